@@ -1,0 +1,124 @@
+/*
+ * reinfocus_hip.h -- C ABI of libreinfocus_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the render-and-measure hot path of jeffwhunter/reinfocus.
+ * The reference has no FFI: its device side is numba @cuda.jit Python.  Each entry
+ * point below names the reference interface it replaces (file:line relative to the
+ * reference checkout); INTEGRATION.md shows the ctypes stub a reference maintainer
+ * would add to bind them.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / numpy types cross the boundary.
+ *  - every function returns 0 on success, a negative rf_status otherwise;
+ *    rf_last_error() returns a thread-local message (HIP errors carry file:line).
+ *  - an rf_ctx owns ALL device memory (RNG states, scene parameters, frames,
+ *    reduction partials) of one renderer on one GPU.  Host buffers are caller-owned.
+ *  - one ctx is not thread-safe; different ctxs (e.g. one per GPU) are independent.
+ *  - calls are synchronous with respect to the host buffers they are handed;
+ *    rf_render(..., NULL) only enqueues (frames stay in HBM).
+ *  - there is NO CPU fallback: without a usable gfx950 device rf_create fails.
+ */
+#ifndef REINFOCUS_HIP_H
+#define REINFOCUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rf_ctx rf_ctx;
+
+typedef enum rf_status {
+    RF_OK = 0,
+    RF_ERR_INVALID = -1,   /* bad argument / call order (maps to AssertionError) */
+    RF_ERR_HIP = -2,       /* HIP runtime error (maps to RuntimeError)           */
+    RF_ERR_NO_DEVICE = -3, /* no usable GPU                                      */
+    RF_ERR_OOM = -4        /* device or pinned-host allocation failed            */
+} rf_status;
+
+/* gray_mode for rf_focus: fixed-point RGB->gray coefficients (vision.py:24,
+ * cv2.cvtColor COLOR_RGB2GRAY).  15 = OpenCV >= 4 (9798/19235/3735 >> 15, the
+ * reference's pinned opencv-python 4.9); 14 = OpenCV 2/3 (4899/9617/1868 >> 14). */
+#define RF_GRAY_15BIT 15
+#define RF_GRAY_14BIT 14
+
+const char *rf_last_error(void);
+int rf_abi_version(void);
+
+/* Number of visible HIP devices (0 on a CPU-only host; never fails the process). */
+int rf_device_count(int *count);
+
+/* Creates the per-renderer context on `device`.
+ * Replaces: FastRenderer.__init__ device-side state (graphics/render.py:127-145). */
+int rf_create(int device, rf_ctx **out);
+int rf_destroy(rf_ctx *ctx);
+
+/* (Re)creates `n_states` xoroshiro128+ states on the device:
+ *   state[i] = jump_2^64 ^ (first_state_index + i) ( splitmix64(seed) ),
+ * bit-identical to numba's sequential host seeding, computed in parallel with a
+ * GF(2) jump-ahead.  first_state_index lets GPU g of a sharded run own the states a
+ * single-device run would have used for its env slice.
+ * Replaces: random.make_random_states (graphics/random.py:8-18) as called from
+ * FastRenderer._make_random_states (graphics/render.py:248-257). */
+int rf_seed(rf_ctx *ctx, uint64_t n_states, uint64_t seed, uint64_t first_state_index);
+int rf_num_states(rf_ctx *ctx, uint64_t *n_states);
+
+/* Checkpoint / test access to the RNG states; layout uint64[count][2] = (s0, s1),
+ * numba's xoroshiro128p_dtype.  No reference counterpart (states are not reachable
+ * through any reference API). */
+int rf_get_states(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t *host_out);
+int rf_set_states(rf_ctx *ctx, uint64_t first, uint64_t count, const uint64_t *host_in);
+
+/* Uploads the scene of `n` environments.
+ *   cam_dyn  float32[n][3][3]  rows: lower_left, horizontal, vertical
+ *   rect     float32[n][2]     (half_side, z_pos)
+ *   origin, u, v  float32[3]   shared camera frame;  lens_radius float64
+ * Replaces: the two cuda.to_device uploads in FastCameras._make_device_data
+ * (graphics/camera.py:144-179) and FastWorlds._make_device_data
+ * (graphics/world.py:110-123); the tuple layout is camera.py:39-56. */
+int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
+                 const float origin[3], const float u[3], const float v[3],
+                 double lens_radius);
+
+/* Renders n frames of h x w pixels with spp samples per pixel into the ctx's frame
+ * buffer (uint8[n][h][w][3], row 0 = bottom of the scene), advancing RNG states
+ * [0, n*h*w).  If host_out is non-NULL the frames are also copied to it.
+ * n must equal the n of the last rf_set_scene; n*h*w must not exceed rf_num_states.
+ * Replaces: FastRenderer.render's launch + copy_to_host (graphics/render.py:165-188)
+ * and the kernel FastRenderer._device_render (graphics/render.py:190-246). */
+int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out);
+
+/* Copies frames [first_env, first_env + n_envs) of the last render to the host. */
+int rf_get_frames(rf_ctx *ctx, int first_env, int n_envs, uint8_t *host_out);
+
+/* Replaces the ctx's frame buffer by caller-supplied images uint8[n][h][w][3], so
+ * that rf_focus can score frames that did not come from rf_render
+ * (vision.focus_values called on a host array, vision.py:28-39). */
+int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in);
+
+/* Focus score of every frame in the ctx's frame buffer:
+ * RGB->gray, 3x3 median (replicate border), 3x3 Laplacian (reflect-101 border,
+ * saturated to uint8), population variance; host_var float64[n].
+ * Replaces: vision.focus_values / focus_value (vision.py:11-39), i.e. the
+ * cv2.cvtColor + cv2.medianBlur + cv2.Laplacian + ndarray.var chain. */
+int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var);
+
+/* rf_render(host_out = NULL) followed by rf_focus: what FocusObserver.observe does
+ * per step (environments/state_observer.py:377-381) without the frame D2H. */
+int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *host_var);
+
+/* Blocks until everything enqueued on the ctx's stream has finished. */
+int rf_synchronize(rf_ctx *ctx);
+
+/* Per-kernel timing with HIP events recorded on the ctx's own stream (bench.py's
+ * roofline figure).  rf_timing(ctx, 1) enables and resets the accumulators;
+ * rf_timing_read synchronizes and returns total milliseconds and launch counts. */
+int rf_timing(rf_ctx *ctx, int enable);
+int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches,
+                   double *focus_ms, uint64_t *focus_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REINFOCUS_HIP_H */

@@ -1,0 +1,224 @@
+"""ctypes access to the CPU oracle (oracle/librf_oracle.so).
+
+TEST INFRASTRUCTURE, not the product: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module.  The product package
+(reinfocus_amd) never does.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librf_oracle.so")
+
+STATE_DTYPE = np.dtype([("s0", np.uint64), ("s1", np.uint64)], align=True)
+
+
+class CamStatic(ctypes.Structure):
+    _fields_ = [
+        ("origin", ctypes.c_float * 3),
+        ("u", ctypes.c_float * 3),
+        ("v", ctypes.c_float * 3),
+        ("lens_radius", ctypes.c_double),
+    ]
+
+
+def build(force=False):
+    """Compiles the oracle with gcc (no FMA contraction)."""
+    src = os.path.join(_HERE, "rf_oracle.c")
+    if (
+        force
+        or not os.path.exists(_SO)
+        or os.path.getmtime(_SO) < os.path.getmtime(src)
+        or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "rf_oracle.h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librf_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        p = ctypes.c_void_p
+        L.orc_seed_states.argtypes = [p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+        L.orc_next.argtypes = [p]
+        L.orc_next.restype = ctypes.c_uint64
+        L.orc_jump.argtypes = [p]
+        L.orc_uniform_float.argtypes = [p]
+        L.orc_uniform_float.restype = ctypes.c_float
+        L.orc_random_in_unit_disc.argtypes = [p, p]
+        L.orc_random_in_unit_sphere.argtypes = [p, p]
+        L.orc_get_ray.argtypes = [p, p, ctypes.c_float, ctypes.c_float, p, p, p]
+        L.orc_uv.argtypes = [p] + [ctypes.c_float] * 4 + [p]
+        L.orc_fast_hit.argtypes = [p, p, p, ctypes.c_float, ctypes.c_float, p]
+        L.orc_fast_hit.restype = ctypes.c_int
+        L.orc_colour_checkerboard.argtypes = [p, p, p]
+        L.orc_scatter.argtypes = [p, p, p, p, p]
+        L.orc_fast_find_colour.argtypes = [p, p, p, p, p]
+        L.orc_render.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int]
+        L.orc_gray.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_int, p]
+        L.orc_median3.argtypes = [p, ctypes.c_int, ctypes.c_int, p]
+        L.orc_laplacian_u8.argtypes = [p, ctypes.c_int, ctypes.c_int, p]
+        L.orc_var_u8.argtypes = [p, ctypes.c_long]
+        L.orc_var_u8.restype = ctypes.c_double
+        L.orc_focus_value.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_focus_value.restype = ctypes.c_double
+        L.orc_focus_values.argtypes = [p] + [ctypes.c_int] * 4 + [p, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def cam_static(origin=(0, 0, 0), u=(1, 0, 0), v=(0, 1, 0), lens_radius=0.05):
+    cs = CamStatic()
+    for k in range(3):
+        cs.origin[k] = origin[k]
+        cs.u[k] = u[k]
+        cs.v[k] = v[k]
+    cs.lens_radius = float(lens_radius)
+    return cs
+
+
+def seed_states(n, seed=0, subsequence_start=0):
+    """graphics/random.py:8-18 make_random_states -> uint64[n, 2] (s0, s1)."""
+    st = np.zeros((int(n), 2), dtype=np.uint64)
+    lib().orc_seed_states(_ptr(st), int(n), int(seed), int(subsequence_start))
+    return st
+
+
+def next_u64(state):
+    return int(lib().orc_next(_ptr(state)))
+
+
+def uniform_float(state):
+    """state: uint64[2] (one row of seed_states), advanced in place."""
+    return np.float32(lib().orc_uniform_float(_ptr(state)))
+
+
+def random_in_unit_disc(state):
+    out = np.zeros(2, dtype=np.float32)
+    lib().orc_random_in_unit_disc(_ptr(state), _ptr(out))
+    return out
+
+
+def random_in_unit_sphere(state):
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_random_in_unit_sphere(_ptr(state), _ptr(out))
+    return out
+
+
+def get_ray(dyn, cs, s, t, state):
+    dyn = _f32(dyn).reshape(9)
+    o = np.zeros(3, dtype=np.float32)
+    d = np.zeros(3, dtype=np.float32)
+    lib().orc_get_ray(_ptr(dyn), ctypes.byref(cs), float(s), float(t), _ptr(state), _ptr(o), _ptr(d))
+    return o, d
+
+
+def uv(point, x_min, x_max, y_min, y_max):
+    pt = _f32(point)
+    out = np.zeros(2, dtype=np.float32)
+    lib().orc_uv(_ptr(pt), x_min, x_max, y_min, y_max, _ptr(out))
+    return out
+
+
+def fast_hit(rect, origin, direction, t_min, t_max):
+    rect, origin, direction = _f32(rect), _f32(origin), _f32(direction)
+    rec = np.zeros(13, dtype=np.float32)
+    hit = lib().orc_fast_hit(_ptr(rect), _ptr(origin), _ptr(direction), t_min, t_max, _ptr(rec))
+    return bool(hit), rec
+
+
+def colour_checkerboard(uf, uv_):
+    uf, uv_ = _f32(uf), _f32(uv_)
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_colour_checkerboard(_ptr(uf), _ptr(uv_), _ptr(out))
+    return out
+
+
+def scatter(rec, state):
+    rec = _f32(rec)
+    o = np.zeros(3, dtype=np.float32)
+    d = np.zeros(3, dtype=np.float32)
+    a = np.zeros(3, dtype=np.float32)
+    lib().orc_scatter(_ptr(rec), _ptr(state), _ptr(o), _ptr(d), _ptr(a))
+    return o, d, a
+
+
+def fast_find_colour(rect, origin, direction, state):
+    rect, origin, direction = _f32(rect), _f32(origin), _f32(direction)
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_fast_find_colour(_ptr(rect), _ptr(origin), _ptr(direction), _ptr(state), _ptr(out))
+    return out
+
+
+def render(cam_dyn, rect, h, w, spp, states, cs=None, n_threads=1):
+    """render.py:190-246 over all pixels; states (uint64[>=n*h*w, 2]) advance in place."""
+    cam_dyn = _f32(cam_dyn)
+    rect = _f32(rect)
+    n = rect.shape[0]
+    assert cam_dyn.shape == (n, 3, 3) and rect.shape == (n, 2)
+    assert states.shape[0] >= n * h * w and states.dtype == np.uint64
+    cs = cs or cam_static()
+    frames = np.zeros((n, h, w, 3), dtype=np.uint8)
+    lib().orc_render(_ptr(frames), n, h, w, spp, _ptr(cam_dyn), _ptr(rect), ctypes.byref(cs),
+                     _ptr(states), n_threads)
+    return frames
+
+
+def gray(rgb, gray_mode=15):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros((h, w), dtype=np.uint8)
+    lib().orc_gray(_ptr(rgb), h, w, gray_mode, _ptr(out))
+    return out
+
+
+def median3(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_median3(_ptr(img), img.shape[0], img.shape[1], _ptr(out))
+    return out
+
+
+def laplacian_u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_laplacian_u8(_ptr(img), img.shape[0], img.shape[1], _ptr(out))
+    return out
+
+
+def var_u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return float(lib().orc_var_u8(_ptr(img), img.size))
+
+
+def focus_value(rgb, gray_mode=15):
+    """vision.py:11-25."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    return float(lib().orc_focus_value(_ptr(rgb), rgb.shape[0], rgb.shape[1], gray_mode))
+
+
+def focus_values(frames, gray_mode=15, n_threads=1):
+    """vision.py:28-39."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w = frames.shape[:3]
+    out = np.zeros(n, dtype=np.float64)
+    lib().orc_focus_values(_ptr(frames), n, h, w, gray_mode, _ptr(out), n_threads)
+    return out

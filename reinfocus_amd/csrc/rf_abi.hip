@@ -1,0 +1,536 @@
+// rf_abi.hip -- C ABI of libreinfocus_hip.so (see include/reinfocus_hip.h).
+//
+// Host-side driver of the gfx950 kernels in rf_kernels.h.  One rf_ctx = one
+// renderer on one GPU: it owns the RNG states, the scene parameters, the frame
+// buffer and the focus partials, all on one HIP stream.  There is no CPU fallback:
+// if no device is usable rf_create fails and says so.
+#include "../../include/reinfocus_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rf_jump.h"
+#include "rf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define RF_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            set_err("%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return _e == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;                   \
+        }                                                                                 \
+    } while (0)
+
+#define RF_REQUIRE(cond, ...)                                                             \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            set_err(__VA_ARGS__);                                                         \
+            return RF_ERR_INVALID;                                                        \
+        }                                                                                 \
+    } while (0)
+
+typedef std::pair<hipEvent_t, hipEvent_t> EventPair;
+
+} // namespace
+
+struct rf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    ulonglong2 *d_states = nullptr;
+    uint64_t n_states = 0;
+    ulonglong2 *d_mats = nullptr;
+
+    float *d_cam = nullptr;
+    float *d_rect = nullptr;
+    int scene_n = 0;
+    int scene_cap = 0;
+    rf::CamStatic cs{};
+    bool axis = false;
+
+    uint8_t *d_frames = nullptr;
+    size_t frames_cap = 0;
+    int fn = 0, fh = 0, fw = 0;
+
+    unsigned long long *d_sums = nullptr;
+    double *d_var = nullptr;
+    int focus_cap = 0;
+
+    rf::CheckerTable tab{};
+
+    bool timing = false;
+    std::vector<EventPair> ev_render, ev_focus;
+    double render_ms = 0.0, focus_ms = 0.0;
+    uint64_t render_n = 0, focus_n = 0;
+};
+
+namespace {
+
+// physics.py:58-62 with uf = 32: sign of sin(fl64(fl64(32*pi) * k/32)) for the 33
+// texture coordinates where 32*u is an integer (see rf_math.h checker_sign).
+rf::CheckerTable make_checker_table()
+{
+    rf::CheckerTable t{0};
+    for (int k = 1; k <= 32; ++k) {
+        const float u = (float)k / 32.0f;
+        const double si = ((double)32.0f * 3.14159265358979323846) * (double)u;
+        if (sin(si) < 0.0)
+            t.neg_mask |= (1ull << k);
+    }
+    return t;
+}
+
+int drain_events(std::vector<EventPair> &evs, double &ms, uint64_t &count)
+{
+    for (EventPair &p : evs) {
+        float t = 0.0f;
+        RF_HIP(hipEventSynchronize(p.second));
+        RF_HIP(hipEventElapsedTime(&t, p.first, p.second));
+        ms += (double)t;
+        count += 1;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    evs.clear();
+    return RF_OK;
+}
+
+struct Timed {
+    rf_ctx *ctx;
+    std::vector<EventPair> *evs;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(rf_ctx *c, std::vector<EventPair> *e) : ctx(c), evs(e)
+    {
+        if (ctx->timing) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (ctx->timing) {
+            (void)hipEventRecord(b, ctx->stream);
+            evs->push_back(EventPair(a, b));
+        }
+    }
+};
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int ensure_frames(rf_ctx *ctx, int n, int h, int w)
+{
+    const size_t need = (size_t)n * h * w * 3 + 64; // + slack for dword tails
+    if (need > ctx->frames_cap) {
+        if (ctx->d_frames)
+            RF_HIP(hipFree(ctx->d_frames));
+        ctx->d_frames = nullptr;
+        ctx->frames_cap = 0;
+        RF_HIP(hipMalloc((void **)&ctx->d_frames, need));
+        ctx->frames_cap = need;
+    }
+    ctx->fn = n;
+    ctx->fh = h;
+    ctx->fw = w;
+    return RF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rf_last_error(void) { return g_err.c_str(); }
+
+int rf_abi_version(void) { return 1; }
+
+int rf_device_count(int *count)
+{
+    RF_REQUIRE(count != nullptr, "rf_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return RF_OK;
+}
+
+int rf_create(int device, rf_ctx **out)
+{
+    RF_REQUIRE(out != nullptr, "rf_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_err("rf_create: no HIP device is visible (%s); libreinfocus_hip has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return RF_ERR_NO_DEVICE;
+    }
+    RF_REQUIRE(device >= 0 && device < count, "rf_create: device %d out of range [0,%d)", device, count);
+    RF_HIP(hipSetDevice(device));
+
+    rf_ctx *ctx = new (std::nothrow) rf_ctx();
+    RF_REQUIRE(ctx != nullptr, "rf_create: out of host memory");
+    ctx->device = device;
+    ctx->tab = make_checker_table();
+
+    std::vector<rf::Mat128> tables;
+    if (!rf::h_build_jump_tables(rf::kSeedMats, tables)) {
+        delete ctx;
+        set_err("rf_create: GF(2) jump matrix disagrees with numba's jump polynomial");
+        return RF_ERR_INVALID;
+    }
+    hipError_t he = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (he == hipSuccess)
+        he = hipMalloc((void **)&ctx->d_mats, sizeof(rf::Mat128) * rf::kSeedMats);
+    if (he == hipSuccess)
+        he = hipMemcpy(ctx->d_mats, tables.data(), sizeof(rf::Mat128) * rf::kSeedMats,
+                       hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        set_err("rf_create: %s", hipGetErrorString(he));
+        rf_destroy(ctx);
+        return he == hipErrorOutOfMemory ? RF_ERR_OOM : RF_ERR_HIP;
+    }
+    *out = ctx;
+    return RF_OK;
+}
+
+int rf_destroy(rf_ctx *ctx)
+{
+    if (!ctx)
+        return RF_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (EventPair &p : ctx->ev_render) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (EventPair &p : ctx->ev_focus) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (ctx->d_states) (void)hipFree(ctx->d_states);
+    if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    if (ctx->d_cam) (void)hipFree(ctx->d_cam);
+    if (ctx->d_rect) (void)hipFree(ctx->d_rect);
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+    if (ctx->d_var) (void)hipFree(ctx->d_var);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RF_OK;
+}
+
+int rf_seed(rf_ctx *ctx, uint64_t n_states, uint64_t seed, uint64_t first_state_index)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_seed: ctx is NULL");
+    RF_REQUIRE(n_states > 0, "rf_seed: n_states must be positive");
+    RF_REQUIRE(first_state_index + n_states < (1ull << rf::kSeedMats),
+               "rf_seed: state index exceeds 2^%d", rf::kSeedMats);
+    RF_HIP(hipSetDevice(ctx->device));
+    if (n_states != ctx->n_states) {
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_states)
+            RF_HIP(hipFree(ctx->d_states));
+        ctx->d_states = nullptr;
+        ctx->n_states = 0;
+        RF_HIP(hipMalloc((void **)&ctx->d_states, n_states * sizeof(ulonglong2)));
+        ctx->n_states = n_states;
+    }
+    const rf::S128 s0 = rf::h_splitmix(seed);
+    const uint64_t per_wave = 64ull * rf::kSeedRun;
+    const uint64_t waves = (n_states + per_wave - 1) / per_wave;
+    const uint64_t blocks = (waves * 64 + rf::kBlock - 1) / rf::kBlock;
+    RF_REQUIRE(blocks < (1ull << 31), "rf_seed: too many states for one launch");
+    hipLaunchKernelGGL(rf::seed_kernel, dim3((unsigned)blocks), dim3(rf::kBlock), 0, ctx->stream,
+                       ctx->d_states, (unsigned long long)n_states,
+                       (unsigned long long)first_state_index, make_ulonglong2(s0.s0, s0.s1),
+                       ctx->d_mats);
+    RF_HIP(hipGetLastError());
+    return RF_OK;
+}
+
+int rf_num_states(rf_ctx *ctx, uint64_t *n_states)
+{
+    RF_REQUIRE(ctx != nullptr && n_states != nullptr, "rf_num_states: NULL argument");
+    *n_states = ctx->n_states;
+    return RF_OK;
+}
+
+int rf_get_states(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr && host_out != nullptr, "rf_get_states: NULL argument");
+    RF_REQUIRE(first + count <= ctx->n_states, "rf_get_states: range [%llu,%llu) exceeds %llu states",
+               (unsigned long long)first, (unsigned long long)(first + count),
+               (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipMemcpyAsync(host_out, ctx->d_states + first, count * sizeof(ulonglong2),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_set_states(rf_ctx *ctx, uint64_t first, uint64_t count, const uint64_t *host_in)
+{
+    RF_REQUIRE(ctx != nullptr && host_in != nullptr, "rf_set_states: NULL argument");
+    RF_REQUIRE(first + count <= ctx->n_states, "rf_set_states: range exceeds %llu states",
+               (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipMemcpyAsync(ctx->d_states + first, host_in, count * sizeof(ulonglong2),
+                          hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
+                 const float origin[3], const float u[3], const float v[3], double lens_radius)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_set_scene: ctx is NULL");
+    RF_REQUIRE(n > 0, "rf_set_scene: n must be positive");
+    RF_REQUIRE(cam_dyn && rect && origin && u && v, "rf_set_scene: NULL argument");
+    RF_HIP(hipSetDevice(ctx->device));
+    if (n > ctx->scene_cap) {
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_cam) RF_HIP(hipFree(ctx->d_cam));
+        if (ctx->d_rect) RF_HIP(hipFree(ctx->d_rect));
+        ctx->d_cam = ctx->d_rect = nullptr;
+        ctx->scene_cap = 0;
+        RF_HIP(hipMalloc((void **)&ctx->d_cam, (size_t)n * 9 * sizeof(float)));
+        RF_HIP(hipMalloc((void **)&ctx->d_rect, (size_t)n * 2 * sizeof(float)));
+        ctx->scene_cap = n;
+    }
+    RF_HIP(hipMemcpyAsync(ctx->d_cam, cam_dyn, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice,
+                          ctx->stream));
+    RF_HIP(hipMemcpyAsync(ctx->d_rect, rect, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice,
+                          ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream)); // host buffers are free again on return
+
+    ctx->cs = rf::CamStatic{origin[0], origin[1], origin[2], u[0], u[1], u[2],
+                            v[0],      v[1],      v[2],      lens_radius};
+    // canonical frame of FastCameras() (camera.py:100-130): enables the AXIS kernel
+    bool axis = origin[0] == 0.0f && origin[1] == 0.0f && origin[2] == 0.0f && u[0] == 1.0f &&
+                u[1] == 0.0f && u[2] == 0.0f && v[0] == 0.0f && v[1] == 1.0f && v[2] == 0.0f;
+    for (int e = 0; axis && e < n; ++e) {
+        const float *c = cam_dyn + (size_t)e * 9;
+        // horizontal = (hx, +0, +0), vertical = (+0, vy, +0)
+        axis = c[4] == 0.0f && c[5] == 0.0f && c[6] == 0.0f && c[8] == 0.0f && !signbit(c[4]) &&
+               !signbit(c[5]) && !signbit(c[6]) && !signbit(c[8]);
+    }
+    ctx->axis = axis;
+    ctx->scene_n = n;
+    return RF_OK;
+}
+
+int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_render: ctx is NULL");
+    RF_REQUIRE(ctx->scene_n > 0, "rf_render: no scene uploaded (rf_set_scene first)");
+    RF_REQUIRE(n == ctx->scene_n, "rf_render: n=%d but the scene holds %d environments", n, ctx->scene_n);
+    RF_REQUIRE(h > 0 && w > 0 && spp > 0, "rf_render: h, w, spp must be positive");
+    RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render: frame too large");
+    const uint64_t need = (uint64_t)n * h * w;
+    RF_REQUIRE(need <= ctx->n_states, "rf_render: %llu pixels but only %llu RNG states (rf_seed first)",
+               (unsigned long long)need, (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_frames(ctx, n, h, w);
+    if (rc != RF_OK)
+        return rc;
+
+    rf::RenderArgs a;
+    a.frames = ctx->d_frames;
+    a.states = ctx->d_states;
+    a.cam_dyn = ctx->d_cam;
+    a.rect = ctx->d_rect;
+    a.cs = ctx->cs;
+    a.tab = ctx->tab;
+    a.n = n;
+    a.h = h;
+    a.w = w;
+    a.spp = spp;
+    a.hw = h * w;
+    a.scale = (float)(255.0 / (double)spp);
+    const bool pow2 = is_pow2(h) && is_pow2(w);
+    a.inv_w = 1.0f / (float)w;
+    a.inv_h = 1.0f / (float)h;
+
+    const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
+    {
+        Timed timed(ctx, &ctx->ev_render);
+        for (int e0 = 0; e0 < n; e0 += 65535) {
+            const int ne = (n - e0) < 65535 ? (n - e0) : 65535;
+            rf::RenderArgs b = a;
+            b.frames = a.frames + (size_t)e0 * a.hw * 3;
+            b.states = a.states + (size_t)e0 * a.hw;
+            b.cam_dyn = a.cam_dyn + (size_t)e0 * 9;
+            b.rect = a.rect + (size_t)e0 * 2;
+            b.n = ne;
+            const dim3 grid(gx, ne), block(rf::kBlock);
+            if (ctx->axis && pow2)
+                hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
+            else if (ctx->axis)
+                hipLaunchKernelGGL((rf::render_kernel<true, false>), grid, block, 0, ctx->stream, b);
+            else if (pow2)
+                hipLaunchKernelGGL((rf::render_kernel<false, true>), grid, block, 0, ctx->stream, b);
+            else
+                hipLaunchKernelGGL((rf::render_kernel<false, false>), grid, block, 0, ctx->stream, b);
+        }
+    }
+    RF_HIP(hipGetLastError());
+    if (ctx->ev_render.size() > 512) {
+        rc = drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
+        if (rc != RF_OK)
+            return rc;
+    }
+    if (host_out)
+        return rf_get_frames(ctx, 0, n, host_out);
+    return RF_OK;
+}
+
+int rf_get_frames(rf_ctx *ctx, int first_env, int n_envs, uint8_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr && host_out != nullptr, "rf_get_frames: NULL argument");
+    RF_REQUIRE(ctx->fn > 0, "rf_get_frames: no frames rendered yet");
+    RF_REQUIRE(first_env >= 0 && n_envs >= 0 && first_env + n_envs <= ctx->fn,
+               "rf_get_frames: env range [%d,%d) exceeds %d frames", first_env, first_env + n_envs, ctx->fn);
+    RF_HIP(hipSetDevice(ctx->device));
+    const size_t per = (size_t)ctx->fh * ctx->fw * 3;
+    RF_HIP(hipMemcpyAsync(host_out, ctx->d_frames + per * first_env, per * n_envs, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in)
+{
+    RF_REQUIRE(ctx != nullptr && host_in != nullptr, "rf_upload_frames: NULL argument");
+    RF_REQUIRE(n > 0 && h > 0 && w > 0, "rf_upload_frames: n, h, w must be positive");
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = ensure_frames(ctx, n, h, w);
+    if (rc != RF_OK)
+        return rc;
+    RF_HIP(hipMemcpyAsync(ctx->d_frames, host_in, (size_t)n * h * w * 3, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var)
+{
+    RF_REQUIRE(ctx != nullptr && host_var != nullptr, "rf_focus: NULL argument");
+    RF_REQUIRE(n > 0 && n <= ctx->fn && h == ctx->fh && w == ctx->fw,
+               "rf_focus: asked for %dx%dx%d but the frame buffer holds %dx%dx%d", n, h, w, ctx->fn, ctx->fh,
+               ctx->fw);
+    RF_REQUIRE(gray_mode == RF_GRAY_15BIT || gray_mode == RF_GRAY_14BIT, "rf_focus: gray_mode must be 14 or 15");
+    const size_t lds = (((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15;
+    RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);
+    RF_HIP(hipSetDevice(ctx->device));
+    if (n > ctx->focus_cap) {
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_sums) RF_HIP(hipFree(ctx->d_sums));
+        if (ctx->d_var) RF_HIP(hipFree(ctx->d_var));
+        ctx->d_sums = nullptr;
+        ctx->d_var = nullptr;
+        ctx->focus_cap = 0;
+        RF_HIP(hipMalloc((void **)&ctx->d_sums, (size_t)n * 2 * sizeof(unsigned long long)));
+        RF_HIP(hipMalloc((void **)&ctx->d_var, (size_t)n * sizeof(double)));
+        ctx->focus_cap = n;
+    }
+    RF_HIP(hipMemsetAsync(ctx->d_sums, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
+    {
+        Timed timed(ctx, &ctx->ev_focus);
+        const int gx = (h + rf::kBand - 1) / rf::kBand;
+        for (int e0 = 0; e0 < n; e0 += 65535) {
+            const int ne = (n - e0) < 65535 ? (n - e0) : 65535;
+            rf::FocusArgs a;
+            a.frames = ctx->d_frames + (size_t)e0 * h * w * 3;
+            a.sums = ctx->d_sums + (size_t)e0 * 2;
+            a.n = ne;
+            a.h = h;
+            a.w = w;
+            a.gray15 = gray_mode == RF_GRAY_15BIT;
+            hipLaunchKernelGGL(rf::focus_kernel, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
+        }
+        hipLaunchKernelGGL(rf::focus_finalize, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_sums,
+                           ctx->d_var, n, (unsigned long long)h * (unsigned long long)w);
+    }
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(host_var, ctx->d_var, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *host_var)
+{
+    int rc = rf_render(ctx, n, h, w, spp, nullptr);
+    if (rc != RF_OK)
+        return rc;
+    return rf_focus(ctx, n, h, w, gray_mode, host_var);
+}
+
+int rf_synchronize(rf_ctx *ctx)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_synchronize: ctx is NULL");
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_timing(rf_ctx *ctx, int enable)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_timing: ctx is NULL");
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    double dummy_ms = 0.0;
+    uint64_t dummy_n = 0;
+    int rc = drain_events(ctx->ev_render, dummy_ms, dummy_n);
+    if (rc == RF_OK)
+        rc = drain_events(ctx->ev_focus, dummy_ms, dummy_n);
+    ctx->render_ms = ctx->focus_ms = 0.0;
+    ctx->render_n = ctx->focus_n = 0;
+    ctx->timing = enable != 0;
+    return rc;
+}
+
+int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches, double *focus_ms,
+                   uint64_t *focus_launches)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_timing_read: ctx is NULL");
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
+    if (rc == RF_OK)
+        rc = drain_events(ctx->ev_focus, ctx->focus_ms, ctx->focus_n);
+    if (render_ms) *render_ms = ctx->render_ms;
+    if (render_launches) *render_launches = ctx->render_n;
+    if (focus_ms) *focus_ms = ctx->focus_ms;
+    if (focus_launches) *focus_launches = ctx->focus_n;
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,295 @@
+// rf_kernels.h -- gfx950 kernels of the render-and-measure path.
+//
+//   render_kernel   FastRenderer._device_render     (graphics/render.py:190-246)
+//   focus_kernel    vision.focus_value chain         (vision.py:23-25), per-env sums
+//   focus_finalize  ndarray.var()                    (vision.py:25)
+//   seed_kernel     make_random_states               (graphics/random.py:8-18)
+//
+// Data layout in HBM (all owned by rf_ctx):
+//   states  uint64x2[n*h*w]   index = e*h*w + y*w + x  (render.py:217) -> a wave's 64
+//                             lanes read/write 1 KiB contiguous (global_*_dwordx4)
+//   frames  uint8[n][h][w][3] lanes along x; 768 B per 256-thread block are staged in
+//                             LDS and leave as 192 coalesced dword stores
+//   cam_dyn float[n][9], rect float[n][2]   per-env parameters (block-uniform)
+//
+// The render kernel is VALU-bound (64-bit integer RNG + rejection loops), not
+// HBM-bound: 38 B/pixel of traffic against ~10^4 lane-ops/pixel at 16 spp.  No MFMA:
+// nothing here is a contraction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rf_math.h"
+
+namespace rf {
+
+constexpr int kBlock = 256;
+
+struct RenderArgs {
+    uint8_t *frames;
+    ulonglong2 *states;
+    const float *cam_dyn; // [n][9]
+    const float *rect;    // [n][2]
+    CamStatic cs;
+    CheckerTable tab;
+    int n, h, w, spp;
+    int hw;          // h*w
+    float scale;     // float32(255.0 / spp)   (render.py:244-246)
+    float inv_w, inv_h; // exact reciprocals when w / h are powers of two
+};
+
+// AXIS / POW2: exact specialisations, see rf_math.h render_pixel.
+template <bool AXIS, bool POW2>
+__global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
+{
+    __shared__ uint32_t stage[kBlock * 3 / 4];
+
+    const int e = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x; // pixel within the env
+    const bool live = p < a.hw;
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    if (live) {
+        const int y = p / a.w;
+        const int x = p - y * a.w;
+        const size_t pix = (size_t)e * a.hw + p;
+
+        const ulonglong2 st = a.states[pix];
+        Rng g{st.x, st.y};
+        const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
+        render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, env, a.cs, a.tab, cr, cg, cb);
+        a.states[pix] = make_ulonglong2(g.s0, g.s1);
+    }
+
+    // uint8 truncation of float32(colour * scale)   (render.py:244-246)
+    const uint8_t r8 = (uint8_t)(cr * a.scale);
+    const uint8_t g8 = (uint8_t)(cg * a.scale);
+    const uint8_t b8 = (uint8_t)(cb * a.scale);
+
+    const size_t block_px = (size_t)e * a.hw + (size_t)blockIdx.x * kBlock;
+    if ((a.hw & 3) == 0) {
+        // 768 B per block -> LDS -> 192 coalesced dword stores (block base is 4-aligned)
+        uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+        sb[threadIdx.x * 3 + 0] = r8;
+        sb[threadIdx.x * 3 + 1] = g8;
+        sb[threadIdx.x * 3 + 2] = b8;
+        __syncthreads();
+        const int count = min(kBlock, a.hw - (int)blockIdx.x * kBlock); // multiple of 4
+        const int ndw = count * 3 / 4;
+        if ((int)threadIdx.x < ndw) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(a.frames + block_px * 3);
+            dst[threadIdx.x] = stage[threadIdx.x];
+        }
+    } else if (live) {
+        uint8_t *dst = a.frames + (block_px + threadIdx.x) * 3;
+        dst[0] = r8;
+        dst[1] = g8;
+        dst[2] = b8;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// focus: gray -> median3x3 (replicate) -> Laplacian (reflect-101, sat u8) -> sums
+// One block per (row band, env).  Integer/byte work, HBM-bound: 3 B/pixel read.
+// ---------------------------------------------------------------------------
+constexpr int kBand = 16; // output rows per block
+
+struct FocusArgs {
+    const uint8_t *frames;
+    unsigned long long *sums; // [n][2] = (sum, sum of squares), zeroed before launch
+    int n, h, w;
+    int gray15; // 1: 15-bit coefficients, 0: 14-bit
+};
+
+__device__ __forceinline__ uint32_t gray_of(uint32_t r, uint32_t g, uint32_t b, int gray15)
+{
+    // vision.py:24 cv2.cvtColor(COLOR_RGB2GRAY), 8-bit fixed point
+    return gray15 ? ((r * 9798u + g * 19235u + b * 3735u + 16384u) >> 15)
+                  : ((r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14);
+}
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1)
+        return 0;
+    if (i < 0)
+        return -i;
+    if (i >= n)
+        return 2 * n - 2 - i;
+    return i;
+}
+
+// dynamic LDS: gray[(kBand+4)][w] then med[(kBand+2)][w]
+__global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int e = blockIdx.y;
+    const int r0 = blockIdx.x * kBand;               // first output row
+    const int r1 = min(r0 + kBand, a.h);             // one past last output row
+    const int w = a.w, h = a.h;
+
+    // median rows needed: reflect101 of [r0-1, r1] -> all inside [m0, m1)
+    const int m0 = max(r0 - 1, 0);
+    const int m1 = min(r1 + 1, h);
+    // gray rows needed for those (replicate border): [g0, g1)
+    const int g0 = max(m0 - 1, 0);
+    const int g1 = min(m1 + 1, h);
+
+    uint8_t *gray = lds;
+    uint8_t *med = lds + (size_t)(kBand + 4) * w;
+
+    const uint8_t *img = a.frames + (size_t)e * h * w * 3;
+
+    const int grows = g1 - g0;
+    if ((w & 3) == 0) {
+        // 4 pixels (12 B = 3 dwords) per thread per step, coalesced
+        const int quads = grows * (w >> 2);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (size_t)g0 * w * 3);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(gray);
+        for (int q = threadIdx.x; q < quads; q += kBlock) {
+            uint32_t d0 = src[3 * q + 0], d1 = src[3 * q + 1], d2 = src[3 * q + 2];
+            uint32_t ga = gray_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, a.gray15);
+            uint32_t gb = gray_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, a.gray15);
+            uint32_t gc = gray_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, a.gray15);
+            uint32_t gd = gray_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, a.gray15);
+            dst[q] = ga | (gb << 8) | (gc << 16) | (gd << 24);
+        }
+    } else {
+        const int px = grows * w;
+        const uint8_t *src = img + (size_t)g0 * w * 3;
+        for (int i = threadIdx.x; i < px; i += kBlock)
+            gray[i] = (uint8_t)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2], a.gray15);
+    }
+    __syncthreads();
+
+    // median rows [m0, m1): cv2.medianBlur(gray, 3), BORDER_REPLICATE
+    const int mrows = m1 - m0;
+    for (int i = threadIdx.x; i < mrows * w; i += kBlock) {
+        const int my = i / w, x = i - my * w;
+        const int y = m0 + my;
+        const int ya = max(y - 1, 0) - g0, yb = y - g0, yc = min(y + 1, h - 1) - g0;
+        const int xa = max(x - 1, 0), xc = min(x + 1, w - 1);
+        uint32_t lo[3], mi[3], hi[3];
+        const int xs[3] = {xa, x, xc};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t v0 = gray[ya * w + xs[c]], v1 = gray[yb * w + xs[c]], v2 = gray[yc * w + xs[c]];
+            lo[c] = min3u(v0, v1, v2);
+            mi[c] = med3u(v0, v1, v2);
+            hi[c] = max3u(v0, v1, v2);
+        }
+        med[i] = (uint8_t)med3u(max3u(lo[0], lo[1], lo[2]), med3u(mi[0], mi[1], mi[2]),
+                                min3u(hi[0], hi[1], hi[2]));
+    }
+    __syncthreads();
+
+    // Laplacian rows [r0, r1): cv2.Laplacian(m, CV_8U), ksize 1, BORDER_REFLECT_101
+    uint32_t s1 = 0;
+    unsigned long long s2 = 0;
+    const int orows = r1 - r0;
+    for (int i = threadIdx.x; i < orows * w; i += kBlock) {
+        const int oy = i / w, x = i - oy * w;
+        const int y = r0 + oy;
+        const int yu = reflect101(y - 1, h) - m0, yd = reflect101(y + 1, h) - m0, yc = y - m0;
+        const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+        int v = (int)med[yu * w + x] + (int)med[yd * w + x] + (int)med[yc * w + xl] +
+                (int)med[yc * w + xr] - 4 * (int)med[yc * w + x];
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        s1 += (uint32_t)v;
+        s2 += (uint32_t)(v * v);
+    }
+
+    // wave reduction (64 lanes) then one atomic pair per wave
+    unsigned long long t1 = s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t1 += __shfl_down(t1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.sums[2 * e + 0], t1);
+        atomicAdd(&a.sums[2 * e + 1], s2);
+    }
+}
+
+// population variance from exact integer sums: (N*S2 - S1^2) / N^2
+__global__ void focus_finalize(const unsigned long long *sums, double *var, int n, unsigned long long npix)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n)
+        return;
+    const unsigned long long s1 = sums[2 * e], s2 = sums[2 * e + 1];
+    const unsigned __int128 num = (unsigned __int128)npix * s2 - (unsigned __int128)s1 * s1;
+    const double dn = (double)npix;
+    var[e] = (double)(unsigned long long)num / (dn * dn);
+}
+
+// ---------------------------------------------------------------------------
+// seeding: state[i] = J^(first + i) * s_init over GF(2), J = 2^64-step jump matrix.
+// mats[k] = J^(2^k) as 128 columns of 128 bits.  A wave owns 64*R consecutive
+// states: lane l starts at base + l and strides by 64 (= mats[6]), so every store
+// instruction writes 1 KiB contiguous.
+// ---------------------------------------------------------------------------
+constexpr int kSeedMats = 48;
+constexpr int kSeedRun = 32;
+
+__device__ __forceinline__ ulonglong2 gf2_matvec(const ulonglong2 *__restrict__ cols, ulonglong2 v)
+{
+    unsigned long long r0 = 0, r1 = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const ulonglong2 c = cols[j];
+        const unsigned long long m = 0ull - ((v.x >> j) & 1ull);
+        r0 ^= c.x & m;
+        r1 ^= c.y & m;
+    }
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+        const ulonglong2 c = cols[64 + j];
+        const unsigned long long m = 0ull - ((v.y >> j) & 1ull);
+        r0 ^= c.x & m;
+        r1 ^= c.y & m;
+    }
+    return make_ulonglong2(r0, r1);
+}
+
+__global__ __launch_bounds__(kBlock) void seed_kernel(ulonglong2 *states, unsigned long long n,
+                                                     unsigned long long first, ulonglong2 s_init,
+                                                     const ulonglong2 *__restrict__ mats)
+{
+    const unsigned long long gid = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long wave = gid >> 6;
+    const unsigned lane = (unsigned)(gid & 63);
+    const unsigned long long base = wave * (64ull * kSeedRun);
+    if (base >= n)
+        return;
+    unsigned long long i = base + lane;
+    const unsigned long long gidx = first + i;
+
+    ulonglong2 s = s_init;
+    for (int k = 0; k < kSeedMats; ++k) {
+        // wave-level skip keeps the matrix loads scalar and skips unused high bits
+        const bool bit = (gidx >> k) & 1ull;
+        if (__any(bit)) {
+            const ulonglong2 t = gf2_matvec(mats + k * 128, s);
+            if (bit)
+                s = t;
+        }
+    }
+    for (int j = 0; j < kSeedRun; ++j) {
+        if (i < n)
+            states[i] = s;
+        i += 64;
+        if (j + 1 < kSeedRun)
+            s = gf2_matvec(mats + 6 * 128, s);
+    }
+}
+
+} // namespace rf

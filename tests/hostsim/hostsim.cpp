@@ -1,0 +1,116 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE.  Compiles the render kernel's per-pixel
+// arithmetic (reinfocus_amd/csrc/rf_math.h, the exact text the gfx950 kernel
+// inlines) for the host, so that CPU-only tests can compare its specialisations
+// (AXIS / POW2 / integer uniform / checker table) with the oracle before any GPU
+// time is spent.  Never loaded by the product package.
+#include <math.h>
+#include <stdint.h>
+
+#include "../../reinfocus_amd/csrc/rf_math.h"
+#include "../../reinfocus_amd/csrc/rf_jump.h"
+
+using namespace rf;
+
+static CheckerTable host_checker_table()
+{
+    CheckerTable t{0};
+    for (int k = 1; k <= 32; ++k) {
+        const float u = (float)k / 32.0f;
+        const double si = ((double)32.0f * 3.14159265358979323846) * (double)u;
+        if (sin(si) < 0.0)
+            t.neg_mask |= (1ull << k);
+    }
+    return t;
+}
+
+extern "C" {
+
+// mode bit0 = AXIS, bit1 = POW2
+int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dyn,
+              const float *rect, const float *origin, const float *u, const float *v,
+              double lens_radius, uint64_t *states, int mode)
+{
+    const CheckerTable tab = host_checker_table();
+    const CamStatic cs{origin[0], origin[1], origin[2], u[0], u[1], u[2], v[0], v[1], v[2], lens_radius};
+    const float scale = (float)(255.0 / (double)spp);
+    const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+    for (int e = 0; e < n; ++e) {
+        const PixelEnv env = make_pixel_env(cam_dyn + 9 * e, rect + 2 * e);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const long pix = ((long)e * h + y) * w + x;
+                Rng g{states[2 * pix], states[2 * pix + 1]};
+                float cr, cg, cb;
+                switch (mode & 3) {
+                case 3: render_pixel<true, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
+                case 1: render_pixel<true, false>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
+                case 2: render_pixel<false, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
+                default: render_pixel<false, false>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
+                }
+                states[2 * pix] = g.s0;
+                states[2 * pix + 1] = g.s1;
+                frames[pix * 3 + 0] = (uint8_t)(cr * scale);
+                frames[pix * 3 + 1] = (uint8_t)(cg * scale);
+                frames[pix * 3 + 2] = (uint8_t)(cb * scale);
+            }
+    }
+    return 0;
+}
+
+// returns the number of mismatches between the integer and literal uniform conversions
+long hs_check_uniform(const uint64_t *words, long n)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        float a = unit_f32_int(words[i]);
+        float b = unit_f32_literal(words[i]);
+        if (!(a == b))
+            ++bad;
+    }
+    return bad;
+}
+
+// pixel_coord_pow2 vs pixel_coord_literal over every x in [0, w) for the given xis
+long hs_check_pixel_coord(const float *xis, long n, int w)
+{
+    long bad = 0;
+    const float inv_w = 1.0f / (float)w;
+    for (int x = 0; x < w; ++x)
+        for (long i = 0; i < n; ++i)
+            if (!(pixel_coord_pow2(x, xis[i], inv_w) == pixel_coord_literal(x, xis[i], w)))
+                ++bad;
+    return bad;
+}
+
+// checker_sign(u) * checker_sign(v) > 0  vs  sin(32 pi u) * sin(32 pi v) > 0
+long hs_check_checker(const float *us, const float *vs, long n)
+{
+    const CheckerTable tab = host_checker_table();
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const double s0 = ((double)32.0f * 3.14159265358979323846) * (double)us[i];
+        const double s1 = ((double)32.0f * 3.14159265358979323846) * (double)vs[i];
+        const bool lit = sin(s0) * sin(s1) > 0.0;
+        const bool fast = (checker_sign(us[i], tab) * checker_sign(vs[i], tab)) > 0;
+        if (lit != fast)
+            ++bad;
+    }
+    return bad;
+}
+
+// GF(2) jump tables: state[index] computed directly vs numba's sequential definition
+int hs_state_at(uint64_t seed, uint64_t index, uint64_t out[2])
+{
+    std::vector<Mat128> tables;
+    if (!h_build_jump_tables(48, tables))
+        return -1;
+    S128 s = h_splitmix(seed);
+    for (int k = 0; k < 48; ++k)
+        if ((index >> k) & 1)
+            s = h_matvec(tables[k], s);
+    out[0] = s.s0;
+    out[1] = s.s1;
+    return 0;
+}
+
+} // extern "C"
