@@ -1,0 +1,211 @@
+"""ctypes binding of libreinfocus_hip.so (include/reinfocus_hip.h).
+
+The HIP library is the only compute path of this package: if it is missing or no GPU
+is usable the calls below raise, loudly.  There is no CPU fallback (the CPU oracle
+under oracle/ is test infrastructure and is never imported from here).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreinfocus_hip.so")
+
+RF_OK = 0
+RF_ERR_INVALID = -1
+RF_ERR_HIP = -2
+RF_ERR_NO_DEVICE = -3
+RF_ERR_OOM = -4
+
+GRAY_15BIT = 15
+GRAY_14BIT = 14
+
+# every symbol include/reinfocus_hip.h declares
+SYMBOLS = (
+    "rf_last_error",
+    "rf_abi_version",
+    "rf_device_count",
+    "rf_create",
+    "rf_destroy",
+    "rf_seed",
+    "rf_num_states",
+    "rf_get_states",
+    "rf_set_states",
+    "rf_set_scene",
+    "rf_render",
+    "rf_get_frames",
+    "rf_upload_frames",
+    "rf_focus",
+    "rf_step",
+    "rf_synchronize",
+    "rf_timing",
+    "rf_timing_read",
+)
+
+
+class NativeLibraryMissing(ImportError):
+    """libreinfocus_hip.so has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and declares the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C reinfocus_amd/csrc` "
+            "(or __graft_entry__.build()); reinfocus_amd has no CPU fallback"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, u64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_double
+    lib.rf_last_error.restype = ctypes.c_char_p
+    lib.rf_last_error.argtypes = []
+    lib.rf_abi_version.argtypes = []
+    lib.rf_device_count.argtypes = [ctypes.POINTER(i32)]
+    lib.rf_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.rf_destroy.argtypes = [vp]
+    lib.rf_seed.argtypes = [vp, u64, u64, u64]
+    lib.rf_num_states.argtypes = [vp, ctypes.POINTER(u64)]
+    lib.rf_get_states.argtypes = [vp, u64, u64, vp]
+    lib.rf_set_states.argtypes = [vp, u64, u64, vp]
+    lib.rf_set_scene.argtypes = [vp, i32, vp, vp, vp, vp, vp, dbl]
+    lib.rf_render.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.rf_get_frames.argtypes = [vp, i32, i32, vp]
+    lib.rf_upload_frames.argtypes = [vp, i32, i32, i32, vp]
+    lib.rf_focus.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.rf_step.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    lib.rf_synchronize.argtypes = [vp]
+    lib.rf_timing.argtypes = [vp, i32]
+    lib.rf_timing_read.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(u64), ctypes.POINTER(dbl),
+                                   ctypes.POINTER(u64)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc == RF_OK:
+        return
+    msg = load().rf_last_error().decode("utf-8", "replace")
+    if rc == RF_ERR_INVALID:
+        raise AssertionError(msg)
+    if rc == RF_ERR_OOM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(load().rf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def default_device():
+    """One process per GPU: torchrun's LOCAL_RANK selects the device."""
+    return int(os.environ.get("REINFOCUS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """Owner of one rf_ctx (one renderer's device state on one GPU)."""
+
+    def __init__(self, device=None):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        dev = default_device() if device is None else int(device)
+        _check(self._lib.rf_create(dev, ctypes.byref(self._h)))
+        self.device = dev
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rf_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    # --- RNG ---------------------------------------------------------------------------
+    def seed(self, n_states, seed=0, first_state_index=0):
+        _check(self._lib.rf_seed(self._h, int(n_states), int(seed), int(first_state_index)))
+
+    def num_states(self):
+        n = ctypes.c_uint64(0)
+        _check(self._lib.rf_num_states(self._h, ctypes.byref(n)))
+        return n.value
+
+    def get_states(self, first=0, count=None):
+        count = self.num_states() - first if count is None else count
+        out = np.zeros((int(count), 2), dtype=np.uint64)
+        _check(self._lib.rf_get_states(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def set_states(self, states, first=0):
+        states = np.ascontiguousarray(states, dtype=np.uint64)
+        assert states.ndim == 2 and states.shape[1] == 2
+        _check(self._lib.rf_set_states(self._h, int(first), states.shape[0], _ptr(states)))
+
+    # --- scene / render / focus ----------------------------------------------------------
+    def set_scene(self, cam_dyn, rect, origin, u, v, lens_radius):
+        cam_dyn = np.ascontiguousarray(cam_dyn, dtype=np.float32)
+        rect = np.ascontiguousarray(rect, dtype=np.float32)
+        n = rect.shape[0]
+        assert cam_dyn.shape == (n, 3, 3), "cam_dyn must be float32[n,3,3]"
+        assert rect.shape == (n, 2), "rect must be float32[n,2]"
+        origin = np.ascontiguousarray(origin, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        _check(self._lib.rf_set_scene(self._h, n, _ptr(cam_dyn), _ptr(rect), _ptr(origin), _ptr(u), _ptr(v),
+                                      float(lens_radius)))
+
+    def render(self, n, h, w, spp, to_host=False):
+        out = np.empty((n, h, w, 3), dtype=np.uint8) if to_host else None
+        _check(self._lib.rf_render(self._h, n, h, w, spp, _ptr(out) if to_host else None))
+        return out
+
+    def get_frames(self, shape, first_env=0, n_envs=None):
+        n, h, w = shape[:3]
+        n_envs = n - first_env if n_envs is None else n_envs
+        out = np.empty((n_envs, h, w, 3), dtype=np.uint8)
+        _check(self._lib.rf_get_frames(self._h, first_env, n_envs, _ptr(out)))
+        return out
+
+    def upload_frames(self, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        assert frames.ndim == 4 and frames.shape[3] == 3, "frames must be uint8[n,h,w,3]"
+        n, h, w = frames.shape[:3]
+        _check(self._lib.rf_upload_frames(self._h, n, h, w, _ptr(frames)))
+
+    def focus(self, n, h, w, gray_mode=GRAY_15BIT):
+        out = np.empty(n, dtype=np.float64)
+        _check(self._lib.rf_focus(self._h, n, h, w, gray_mode, _ptr(out)))
+        return out
+
+    def step(self, n, h, w, spp, gray_mode=GRAY_15BIT):
+        out = np.empty(n, dtype=np.float64)
+        _check(self._lib.rf_step(self._h, n, h, w, spp, gray_mode, _ptr(out)))
+        return out
+
+    def synchronize(self):
+        _check(self._lib.rf_synchronize(self._h))
+
+    def timing(self, enable=True):
+        _check(self._lib.rf_timing(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        rm, fm = ctypes.c_double(0), ctypes.c_double(0)
+        rn, fn = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._lib.rf_timing_read(self._h, ctypes.byref(rm), ctypes.byref(rn), ctypes.byref(fm),
+                                        ctypes.byref(fn)))
+        return {"render_ms": rm.value, "render_launches": rn.value, "focus_ms": fm.value,
+                "focus_launches": fn.value}

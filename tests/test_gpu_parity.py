@@ -1,0 +1,298 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+committed numpy-1.26 golden vectors.  Bit-exact for frames and RNG states; focus
+values to 1e-9 relative (integer-exact sums vs numpy's pairwise float64 variance),
+far inside the 1e-4 absolute tolerance BASELINE.json states."""
+
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from reinfocus_amd import _native
+
+    assert _native.device_count() >= 1, "no GPU visible: the HIP path cannot run"
+    return _native
+
+
+@pytest.fixture()
+def ctx(native):
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+# --- seeding -------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("n,first", [(1, 0), (63, 0), (64, 0), (5000, 0), (3000, 123457)])
+def test_seed_matches_sequential_jumps(ctx, oracle, n, first):
+    """rf_seed's GF(2) jump-ahead == numba's sequential host seeding (random.py:8-18)."""
+    ctx.seed(n, 0, first)
+    want = oracle.seed_states(first + n, 0)[first:]
+    assert np.array_equal(ctx.get_states(), want)
+
+
+def test_seed_far_offset(ctx):
+    """State indices beyond what the sequential oracle can reach in seconds (the 8-GPU
+    shard offsets): compare with the host GF(2) tables, which tests/test_host_logic.py
+    pins against sequential jumps."""
+    import ctypes
+
+    hs = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "hostsim", "libhostsim.so"))
+    hs.hs_state_at.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    n, first = 2049, 2**31 + 5
+    ctx.seed(n, 0, first)
+    got = ctx.get_states()
+    out = np.zeros(2, dtype=np.uint64)
+    for i in (0, 1, 63, 64, 65, 2047, 2048):
+        assert hs.hs_state_at(0, first + i, out.ctypes.data) == 0
+        assert np.array_equal(got[i], out)
+
+
+def test_seed_other_seed(ctx, oracle):
+    ctx.seed(777, 7, 0)
+    assert np.array_equal(ctx.get_states(), oracle.seed_states(777, 7))
+
+
+# --- render: golden vectors ------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["render_pow2", "render_npot", "render_rsize30", "render_cfg1", "render_mid"])
+def test_render_golden(native, golden_dir, name):
+    """FastRenderer (HIP) reproduces the numpy-1.26 restatement bit for bit."""
+    from reinfocus_amd.graphics import render
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h, spp = int(g["h"]), int(g["spp"])
+    r = render.FastRenderer(samples_per_pixel=spp, r_size=float(g["r_size"]), device=0)
+    r.update_targets(g["targets"])
+    r.update_focus_planes(g["focus"])
+    for p in range(int(g["passes"])):
+        frames = np.asarray(r.render(h))
+        assert frames.shape == g["frames%d" % p].shape and frames.dtype == np.uint8
+        assert np.array_equal(frames, g["frames%d" % p])
+    n = len(g["targets"])
+    assert np.array_equal(r._ctx.get_states(0, n * h * h), g["states_after"])
+
+
+# --- render: oracle on seeded random scenes ---------------------------------------------------
+
+
+@pytest.mark.parametrize(
+    "n,h,w,spp",
+    [
+        (8, 64, 64, 4),      # AXIS + POW2
+        (3, 100, 100, 3),    # AXIS, non power of two (f64 s/t)
+        (5, 33, 35, 2),      # h*w odd: byte-store epilogue
+        (2, 128, 32, 5),     # h != w, both powers of two
+        (1, 300, 300, 1),    # reference default frame height
+        (256, 16, 16, 2),    # many small envs
+    ],
+)
+def test_render_matches_oracle(ctx, oracle, n, h, w, spp):
+    rng = np.random.default_rng(n * 1000 + h)
+    targets, focus = helpers.random_scene(rng, n)
+    dyn, rect, origin, u, v, lens = helpers.pack_scene(targets, focus)
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(dyn, rect, h, w, spp, st, n_threads=8)
+    ctx.seed(n * h * w, 0, 0)
+    ctx.set_scene(dyn, rect, origin, u, v, lens)
+    got = ctx.render(n, h, w, spp, to_host=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.get_states(0, n * h * w), st)
+    # second pass continues the same streams
+    want2 = oracle.render(dyn, rect, h, w, spp, st, n_threads=8)
+    got2 = ctx.render(n, h, w, spp, to_host=True)
+    assert np.array_equal(got2, want2)
+
+
+@pytest.mark.parametrize("h,w", [(32, 32), (24, 40)])
+def test_render_general_camera_matches_oracle(ctx, oracle, h, w):
+    """A camera frame that is not the canonical one takes the general kernel."""
+    from reinfocus_amd.graphics import camera, world
+
+    n, spp = 3, 4
+    cams = camera.FastCameras(look_from=(0.5, -0.25, 1.0), look_at=(0.3, 0.2, -9.0), up=(0.1, 1.0, 0.05),
+                              aperture=0.3, vfov=35, aspect_ratio=1.5)
+    cams.update([6.0, 8.5, 9.75])
+    worlds = world.FastWorlds(25)
+    worlds.update([7.0, 8.5, 6.0])
+    dyn, origin, u, v, lens = cams.device_data()
+    rect = worlds.device_data()
+    cs = oracle.cam_static(origin, u, v, float(lens))
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(dyn, rect, h, w, spp, st, cs=cs)
+    ctx.seed(n * h * w, 0, 0)
+    ctx.set_scene(dyn, rect, origin, u, v, float(lens))
+    got = ctx.render(n, h, w, spp, to_host=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
+def test_render_extreme_geometry(ctx, oracle):
+    """Targets far outside [5, 10]: tiny/huge rectangles, strong defocus, t-range misses."""
+    targets = np.array([1.0, 40.0, 0.0005, 2.0e6, 10.0, 5.0], dtype=np.float32)
+    focus = np.array([40.0, 1.0, 10.0, 10.0, 0.01, 1.0e4], dtype=np.float32)
+    n, h, w, spp = len(targets), 32, 32, 3
+    dyn, rect, origin, u, v, lens = helpers.pack_scene(targets, focus)
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(dyn, rect, h, w, spp, st)
+    ctx.seed(n * h * w, 0, 0)
+    ctx.set_scene(dyn, rect, origin, u, v, lens)
+    assert np.array_equal(ctx.render(n, h, w, spp, to_host=True), want)
+    assert np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
+def test_partial_render_reuses_low_state_indices(ctx, oracle):
+    """Auto-reset renders k < N envs with states 0..k*h*w (vector_environment.py:144,
+    render.py:217): the HIP path must consume exactly those streams."""
+    n, k, h, spp = 6, 2, 32, 3
+    rng = np.random.default_rng(5)
+    t, f = helpers.random_scene(rng, n)
+    st = oracle.seed_states(n * h * h, 0)
+    ctx.seed(n * h * h, 0, 0)
+    d = helpers.pack_scene(t, f)
+    oracle.render(d[0], d[1], h, h, spp, st)
+    ctx.set_scene(*d)
+    ctx.render(n, h, h, spp)
+    t2, f2 = helpers.random_scene(rng, k)
+    d2 = helpers.pack_scene(t2, f2)
+    want = oracle.render(d2[0], d2[1], h, h, spp, st)
+    ctx.set_scene(*d2)
+    got = ctx.render(k, h, h, spp, to_host=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.get_states(), st)
+
+
+# --- focus -----------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize(
+    "n,h,w",
+    [(4, 64, 64), (3, 300, 300), (5, 33, 35), (2, 17, 100), (7, 2, 2), (3, 1, 9), (2, 9, 1), (1, 256, 256),
+     (2, 16, 16), (2, 15, 20), (1, 600, 600)],
+)
+@pytest.mark.parametrize("gray_mode", [15, 14])
+def test_focus_matches_oracle(ctx, oracle, n, h, w, gray_mode):
+    rng = np.random.default_rng(h * 7 + w)
+    frames = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+    # one smooth image so that the median/Laplacian see structure, one constant
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames[0, :, :, 0] = (xx * 3 + yy * 5) % 256
+    if n > 1:
+        frames[1] = 77
+    ctx.upload_frames(frames)
+    got = ctx.focus(n, h, w, gray_mode)
+    want = oracle.focus_values(frames, gray_mode)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    if n > 1:
+        assert got[1] == 0.0
+
+
+def test_focus_of_rendered_frames(ctx, oracle):
+    n, h, spp = 6, 128, 4
+    targets = np.full(n, 8.0, dtype=np.float32)
+    focus = np.array([5.0, 6.5, 8.0, 9.0, 10.0, 7.5], dtype=np.float32)
+    d = helpers.pack_scene(targets, focus)
+    st = oracle.seed_states(n * h * h, 0)
+    frames = oracle.render(d[0], d[1], h, h, spp, st, n_threads=8)
+    want = oracle.focus_values(frames)
+    ctx.seed(n * h * h, 0, 0)
+    ctx.set_scene(*d)
+    got = ctx.step(n, h, h, spp)
+    assert np.max(np.abs(got - want)) < 1e-4          # BASELINE.json tolerance
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)  # what we actually achieve
+    assert np.argmax(got) == 2                         # in focus where focus == target
+
+
+# --- the Python surface ---------------------------------------------------------------------
+
+
+def test_fast_renderer_and_vision_surface(native, oracle):
+    """tests/vision_test.py:40-56 of the reference, on the HIP path, plus oracle parity."""
+    from reinfocus_amd import vision
+    from reinfocus_amd.graphics import render
+
+    r = render.FastRenderer(samples_per_pixel=8, device=0)
+    r.update_targets([10] * 5)
+    r.update_focus_planes([40, 20, 10, 5, 1])
+    frames = r.render(96)
+    fv = vision.focus_values(frames)            # device-resident path
+    assert fv[2] > fv[3] > fv[4] and fv[2] > fv[1] > fv[0]
+    host = np.asarray(frames)
+    assert host.shape == (5, 96, 96, 3) and host.dtype == np.uint8
+    fv_host = vision.focus_values(host)         # upload path
+    assert np.allclose(fv, fv_host, rtol=0, atol=0)
+    want = oracle.focus_values(host)
+    assert np.allclose(fv, want, rtol=1e-9, atol=1e-9)
+    assert abs(vision.focus_value(host[2]) - want[2]) < 1e-9 * max(1.0, want[2])
+
+
+def test_vision_known_answers(native):
+    """tests/vision_test.py:14-34 of the reference."""
+    from reinfocus_amd import vision
+
+    assert vision.focus_value(np.zeros((10, 10, 3), dtype=np.uint8)) == 0
+    assert vision.focus_value(np.ones((10, 10, 3), dtype=np.uint8)) == 0
+    frame = np.zeros((10, 10, 3), dtype=np.uint8)
+    frame[0:10:2, :, :] = 255
+    frame[:, 0:10:2, :] = 255 - frame[:, 0:10:2, :]
+    assert vision.focus_value(frame) > 1
+
+
+def test_render_known_answers(native):
+    """tests/graphics/render_test.py:83-116 of the reference (FastRendererTest)."""
+    from reinfocus_amd.graphics import render
+
+    testee = render.FastRenderer(r_size=30, device=0)
+    testee.update_targets([10])
+    testee.update_focus_planes([10])
+    avg = np.average(np.asarray(testee.render(300)), axis=(0, 1, 2))
+    assert np.all(avg >= np.multiply([0.25, 0.25, 0], 255))
+    assert np.all(avg <= np.multiply([0.5, 0.5, 0], 255))
+
+    grow = render.FastRenderer(samples_per_pixel=4, device=0)
+    grow.update_targets([10])
+    grow.update_focus_planes([10])
+    grow.render(300)
+    grow.render(600)
+    result = np.asarray(grow.render(300))
+    assert result.shape == (1, 300, 300, 3)
+    assert grow._ctx.num_states() == 600 * 600
+
+
+def test_device_frames_survive_next_render(native):
+    from reinfocus_amd.graphics import render
+
+    r = render.FastRenderer(samples_per_pixel=2, device=0)
+    r.update_targets([7.0, 8.0])
+    r.update_focus_planes([7.0, 8.0])
+    a = r.render(32)
+    b = r.render(32)
+    assert not a.is_resident() and b.is_resident()
+    assert np.asarray(a).shape == (2, 32, 32, 3)
+    assert not np.array_equal(np.asarray(a), np.asarray(b))  # RNG streams advanced
+
+
+def test_errors_are_loud(native, ctx):
+    with pytest.raises(AssertionError):
+        ctx.render(1, 8, 8, 1)  # no scene
+    d = helpers.pack_scene([7.0], [7.0])
+    ctx.set_scene(*d)
+    with pytest.raises(AssertionError):
+        ctx.render(1, 8, 8, 1)  # no states
+    ctx.seed(64, 0, 0)
+    with pytest.raises(AssertionError):
+        ctx.render(2, 8, 8, 1)  # n mismatch
+    with pytest.raises(AssertionError):
+        ctx.render(1, 16, 16, 1)  # not enough states
+    ctx.render(1, 8, 8, 1)
+    with pytest.raises(AssertionError):
+        ctx.focus(1, 16, 16)  # shape mismatch with the frame buffer
