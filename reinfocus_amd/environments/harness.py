@@ -1,0 +1,249 @@
+"""Thin vector-environment harness for the DiscreteSteps-v0 task.
+
+The reference assembles this environment from six strategy objects
+(examples/custom_environments.py:114-241 on top of
+reinfocus/environments/vector_environment.py:19-176).  Only one of them touches the
+GPU (FocusObserver); the others are O(N) numpy glue that SURVEY.md section 8 marks out
+of scope for re-implementation.  The benchmark still has to *step* an environment, so
+this module reproduces the reference's call order and numpy arithmetic for exactly that
+task, vectorised, in one place:
+
+    step:  transform -> ender.step -> observe (render + focus on the GPU) -> reward ->
+           terminated/truncated -> same-step auto-reset of the done envs (partial render)
+
+State is float32[N, 2] = [target position, focus plane]; observations are
+float32[N, 4] = [focus plane, focus value, their changes], normalised to [-1, 1].
+Deliberate difference: the reference's RangedInitializer is unseeded
+(state_initializer.py:50); here `seed` makes runs reproducible.
+"""
+
+import numpy as np
+
+from reinfocus_amd.environments import spaces
+from reinfocus_amd.environments import state_observer
+from reinfocus_amd.graphics import render
+
+TARGET, FOCUS = 0, 1  # state element indices (custom_environments.py:169-171)
+
+
+class _Initializer:
+    """Uniform states in `ends` (state_initializer.py:30-71, vectorised and seedable)."""
+
+    def __init__(self, ends, seed):
+        self._ends = ends
+        self._generator = np.random.Generator(np.random.PCG64DXSM(seed))
+
+    def initialize(self, num_envs):
+        return self._generator.uniform(self._ends[0], self._ends[1], size=(num_envs, 2)).astype(np.float32)
+
+
+class _Ender:
+    """TimeLimitEnder | DivergingEnder (episode_ender.py:580-656, :106-207, :369-452);
+    max_steps None leaves only the diverging rule (the non-vector DiscreteSteps)."""
+
+    def __init__(self, num_envs, max_steps, threshold, early_end_steps):
+        self._num_envs = num_envs
+        self._max_steps = max_steps
+        self._threshold = threshold
+        self._early_end_steps = early_end_steps
+        self._steps = np.zeros(num_envs, dtype=np.int32)
+        self._diverging_steps = np.zeros(num_envs, dtype=np.int32)
+        self._last_diff = np.zeros(num_envs, dtype=np.float32)
+
+    def step(self, states):
+        self._steps += 1
+        diff = abs(states[:, TARGET] - states[:, FOCUS])
+        self._diverging_steps[diff > self._last_diff + self._threshold] += 1
+        self._last_diff = diff
+
+    def is_terminated(self):
+        return np.full(self._num_envs, False)
+
+    def is_truncated(self):
+        truncated = self._diverging_steps >= self._early_end_steps
+        if self._max_steps is not None:
+            truncated = (self._steps >= self._max_steps) | truncated
+        return truncated
+
+    def reset(self, states, indices=None):
+        if indices is None:
+            indices = np.full(self._num_envs, True)
+        self._steps[indices] = 0
+        self._diverging_steps[indices] = 0
+        self._last_diff[indices] = abs(states[:, TARGET] - states[:, FOCUS])
+
+
+class _Observer:
+    """NormalizedObserver(DeltaObserver([IndexedElementObserver, FocusObserver], True,
+    [max_move, nan])) -- state_observer.py:166-292, :386-517."""
+
+    def __init__(self, num_envs, ends, max_move, focus_observer):
+        self._focus = focus_observer
+        lows = np.array([ends[0], focus_observer.single_observation_space.low[0]], dtype=np.float32)
+        highs = np.array([ends[1], focus_observer.single_observation_space.high[0]], dtype=np.float32)
+        diff = highs - lows
+        diff[0] = max_move
+        low = np.append(lows, -diff)
+        high = np.append(highs, diff)
+        spans = np.vstack([low, high]).astype(np.float32)
+        self._mid = np.average(spans, axis=0)
+        self._scale = np.diff(spans / 2, axis=0).reshape(4)
+        self._old = np.full((num_envs, 2), np.nan, dtype=np.float32)
+        self._num_envs = num_envs
+        self.single_observation_space = spaces.Box(-np.ones(4, dtype=np.float32), np.ones(4, dtype=np.float32),
+                                                   dtype=np.float32)
+        self.observation_space = spaces.batch_space(self.single_observation_space, num_envs)
+
+    def _wrapped(self, states, indices):
+        position = states[:, FOCUS].reshape((indices.sum(), 1))
+        return np.hstack([position, self._focus.observe(states, indices)], dtype=np.float32)
+
+    def _normalize(self, values):
+        return np.clip((values - self._mid) / self._scale, -1, 1, dtype=np.float32)
+
+    def observe(self, states, indices=None):
+        if indices is None:
+            indices = np.full(self._num_envs, True)
+        wrapped = self._wrapped(states, indices)
+        observations = np.hstack([wrapped, wrapped - self._old[indices]], dtype=np.float32)
+        self._old[indices] = wrapped
+        return self._normalize(observations)
+
+    def reset(self, states, indices=None):
+        if indices is None:
+            indices = np.full(self._num_envs, True)
+        wrapped = self._wrapped(states, indices)
+        observations = np.hstack([wrapped, np.zeros(wrapped.shape, dtype=np.float32)], dtype=np.float32)
+        self._old[indices] = wrapped
+        return self._normalize(observations)
+
+
+class _Rewarder:
+    """DeltaRewarder + ObservationRewarder + OnTargetRewarder
+    (episode_rewarder.py:86-155, :210-292)."""
+
+    def __init__(self, scale, span, focus_value_o_index=1):
+        self._scale = scale
+        self._span = span
+        self._o_index = focus_value_o_index
+        self._old_states = None
+
+    def reset(self, states, observations, indices=None):
+        if self._old_states is not None and indices is not None:
+            self._old_states[indices] = states[:, FOCUS]
+        else:
+            self._old_states = states[:, FOCUS]
+
+    def reward(self, states, observations):
+        moved = abs(states[:, FOCUS] - self._old_states) * -1.0 / self._scale
+        self._old_states = states[:, FOCUS]
+        on_target = (abs(states[:, TARGET] - states[:, FOCUS]) < self._span) * 1.0 + 0.0
+        return (moved + observations[:, self._o_index]) + on_target
+
+
+class VectorDiscreteSteps:
+    """The DiscreteSteps-v0 vector environment (custom_environments.py:114-241) on the
+    MI355X render path.  Same constructor arguments and defaults as the reference;
+    frame_height / samples_per_pixel / seed / device / first_state_index are extensions
+    (defaults = the reference's 300 px, 100 spp, device LOCAL_RANK)."""
+
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
+
+    def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
+                 samples_per_pixel=100, seed=None, device=None, first_state_index=0, _diverging_only=False):
+        ends = (5.0, 10.0)
+        target_radius = 0.25
+        max_move = 5.0
+        moves = max_move / 2.0 ** np.arange(6)
+
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        self.render_mode = render_mode
+        self.num_envs = num_envs
+
+        self._renderer = render.FastRenderer(samples_per_pixel=samples_per_pixel, device=device,
+                                             first_state_index=first_state_index)
+        self._ender = _Ender(num_envs, None if _diverging_only else max_episode_steps, target_radius / 2, 3)
+        self._initializer = _Initializer(ends, seed)
+        self._focus_observer = state_observer.FocusObserver(num_envs, TARGET, FOCUS, ends, self._renderer,
+                                                            frame_height)
+        self._observer = _Observer(num_envs, ends, max_move, self._focus_observer)
+        self._rewarder = _Rewarder(target_radius * 2, target_radius)
+        # DiscreteMoveTransformer (state_transformer.py:222-266)
+        self._action_set = np.concatenate([-moves, [0], moves[::-1]])
+        self._limits = ends
+
+        self.single_action_space = spaces.Discrete(len(self._action_set))
+        self.action_space = spaces.batch_space(self.single_action_space, num_envs)
+        self.single_observation_space = self._observer.single_observation_space
+        self.observation_space = self._observer.observation_space
+        self._state = None
+
+    # -- vector_environment.py:75-102 ------------------------------------------------------
+    def reset(self, *, seed=None, options=None, state=None):
+        """`state` (extension) pins the initial state instead of drawing it."""
+        if seed is not None:
+            self._initializer = _Initializer(self._limits, seed)
+        self._state = (self._initializer.initialize(self.num_envs) if state is None
+                       else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
+        self._ender.reset(self._state)
+        observations = self._observer.reset(self._state, None)
+        self._rewarder.reset(self._state, observations)
+        return observations, {}
+
+    def _transform(self, states, actions):
+        new_states = states.copy()
+        new_states[:, FOCUS] += self._action_set[np.asarray(actions).flatten()]
+        return np.clip(new_states, *self._limits)
+
+    # -- vector_environment.py:104-164 -------------------------------------------------------
+    def step(self, actions):
+        assert self._state is not None
+        self._state = self._transform(self._state, actions)
+        self._ender.step(self._state)
+        observations = self._observer.observe(self._state)
+        rewards = self._rewarder.reward(self._state, observations)
+        terminated = self._ender.is_terminated()
+        truncated = self._ender.is_truncated()
+        done = terminated | truncated
+        if done.any():
+            new_state = self._initializer.initialize(done.sum())
+            self._state[done] = new_state
+            self._ender.reset(new_state, done)
+            new_observations = self._observer.reset(new_state, done)
+            observations[done] = new_observations
+            self._rewarder.reset(new_state, new_observations, done)
+        return observations, rewards, terminated, truncated, {}
+
+    def render(self):
+        """vector_environment.py:166-176 -> HistoryVisualizer.visualize
+        (episode_visualizer.py:188-197): only its renderer.render(600) call belongs to
+        the hot path (it advances / re-seeds the RNG states); the matplotlib compositing
+        is out of scope, the frames are returned as they are."""
+        if self.render_mode == "rgb_array":
+            return np.asarray(self._renderer.render(600))
+        return None
+
+    def close(self):
+        self._renderer._ctx.close()
+
+
+class DiscreteSteps(VectorDiscreteSteps):
+    """The single-environment DiscreteSteps (custom_environments.py:16-111 on
+    environments/environment.py): one env, DivergingEnder only, unbatched returns."""
+
+    def __init__(self, render_mode=None, **kwargs):
+        super().__init__(num_envs=1, render_mode=render_mode, _diverging_only=True, **kwargs)
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+
+    def reset(self, *, seed=None, options=None, state=None):
+        observations, info = super().reset(seed=seed, options=options, state=state)
+        return observations[0], info
+
+    def step(self, action):
+        # environment.py: no auto-reset in the single-env shell
+        self._state = self._transform(self._state, np.array([action]))
+        self._ender.step(self._state)
+        observations = self._observer.observe(self._state)
+        reward = self._rewarder.reward(self._state, observations)[0]
+        return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}

@@ -1,0 +1,48 @@
+"""Environment ids of the reference's examples (examples/__init__.py:6-18).
+
+`DiscreteSteps-v0` is registered with gymnasium when gymnasium is importable (same id,
+entry_point + vector_entry_point, max_episode_steps=20), and is always available through
+the local make()/make_vec() below, which accept the same arguments as
+gymnasium.make / gymnasium.make_vec(id, num_envs, vectorization_mode="custom", vector_kwargs=...).
+`ContinuousJumps-v0` needs strategy objects outside the hot path and is not provided.
+"""
+
+from reinfocus_amd.environments import harness
+
+ENTRY_POINTS = {
+    "DiscreteSteps-v0": {
+        "entry_point": "reinfocus_amd.environments.harness:DiscreteSteps",
+        "vector_entry_point": "reinfocus_amd.environments.harness:VectorDiscreteSteps",
+        "max_episode_steps": 20,
+    },
+}
+
+
+def register_with_gymnasium():
+    """Registers the ids with gymnasium; returns False when gymnasium is not installed."""
+    try:
+        from gymnasium.envs import registration
+    except ImportError:
+        return False
+    for env_id, spec in ENTRY_POINTS.items():
+        if env_id not in registration.registry:
+            registration.register(id=env_id, **spec)
+    return True
+
+
+def make(env_id, **kwargs):
+    if env_id != "DiscreteSteps-v0":
+        raise KeyError(f"{env_id} is not provided by reinfocus_amd (only DiscreteSteps-v0)")
+    return harness.DiscreteSteps(**kwargs)
+
+
+def make_vec(env_id, num_envs=1, vectorization_mode="custom", vector_kwargs=None, **kwargs):
+    if env_id != "DiscreteSteps-v0":
+        raise KeyError(f"{env_id} is not provided by reinfocus_amd (only DiscreteSteps-v0)")
+    args = {"max_episode_steps": ENTRY_POINTS[env_id]["max_episode_steps"]}
+    args.update(vector_kwargs or {})
+    args.update(kwargs)
+    return harness.VectorDiscreteSteps(num_envs=num_envs, **args)
+
+
+register_with_gymnasium()

@@ -1,0 +1,92 @@
+"""GPU tests of the caller side: FocusObserver and the DiscreteSteps-v0 harness."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_notebook_outputs():
+    """examples/environment.ipynb of the reference holds real outputs of the reference
+    itself (numba on CUDA + OpenCV 4.9): DiscreteSteps(render_mode="rgb_array"),
+    reset() -> [0.46703607, -0.84483975, 0, 0]; render(); step(8) ->
+    ([0.59203607, -0.873161, 0.0625, -0.01416067], -1.4981610774993896, False, False)
+    with final state [[5.311405, 8.98009]].  The initial state is recovered from those
+    numbers (the reference's initializer is unseeded); everything else -- seed-0 RNG
+    states, the 13-env extrema render, the 300 px render, the 600 px render that re-seeds,
+    the next 300 px render, gray/median/Laplacian/var, normalisation -- must reproduce
+    the printed digits exactly."""
+    from reinfocus_amd.environments import harness
+
+    env = harness.DiscreteSteps(render_mode="rgb_array", device=0)
+    obs, _ = env.reset(state=[[5.311405, 8.66759]])
+    assert obs.dtype == np.float32
+    # the notebook shows numpy's 8-digit array repr: compare in that representation
+    assert repr(obs) == "array([ 0.46703607, -0.84483975,  0.        ,  0.        ], dtype=float32)"
+    frames = env.render()
+    assert frames.shape == (1, 600, 600, 3)
+    obs, reward, terminated, truncated, _ = env.step(8)
+    assert repr(obs) == "array([ 0.59203607, -0.873161  ,  0.0625    , -0.01416067], dtype=float32)"
+    assert reward == -1.4981610774993896
+    assert not terminated and not truncated
+    assert np.array_equal(env._state, np.array([[5.311405, 8.98009]], dtype=np.float32))
+    env.close()
+
+
+def test_focus_observer_contract():
+    """tests/environments/state_observer_test.py:424-480 of the reference."""
+    from reinfocus_amd.environments import state_observer
+    from reinfocus_amd.graphics import render
+
+    num_envs = 5
+    ends = (5, 10)
+    renderer = render.FastRenderer(device=0)  # 100 spp, as the reference's test
+    testee = state_observer.FocusObserver(num_envs, 0, 1, ends, renderer)  # 300 px
+    assert np.all(testee.single_observation_space.low < testee.single_observation_space.high)
+    assert testee.observation_space.shape == (num_envs, 1)
+
+    # focus plane approaching the target from either side: focus value must rise
+    for mid_point in np.linspace(*ends, num_envs):
+        state = np.vstack([np.linspace(ends[0], mid_point, num_envs),
+                           np.linspace(ends[1], mid_point, num_envs)]).T.astype(np.float32)
+        fv = testee.observe(state)
+        assert fv.shape == (num_envs, 1) and fv.dtype == np.float64
+        gaps = np.abs(state[:, 0] - state[:, 1])
+        order = np.argsort(-gaps, kind="stable")
+        distinct = gaps[order][:-1] - gaps[order][1:] > 0.3
+        assert np.all((fv[order, 0][1:] > fv[order, 0][:-1])[distinct])
+
+    indices = np.array([True, False, True, False, True])
+    part = testee.observe(np.array([[5, 10], [7.5, 10], [10, 10]], dtype=np.float32), indices)
+    assert part.shape == (3, 1)
+    assert np.all(part[1:] > part[:-1])
+    part = testee.reset(np.array([[5, 10], [10, 10]], dtype=np.float32), np.array([True, False, False, False, True]))
+    assert part.shape == (2, 1)
+
+
+def test_vector_environment_steps_and_auto_resets(oracle):
+    from reinfocus_amd import registration
+
+    n = 64
+    env = registration.make_vec("DiscreteSteps-v0", num_envs=n, vectorization_mode="custom",
+                                vector_kwargs={"frame_height": 32, "samples_per_pixel": 4, "seed": 3, "device": 0})
+    obs, info = env.reset()
+    assert obs.shape == (n, 4) and obs.dtype == np.float32 and info == {}
+    assert np.all(obs[:, 2:] == 0) and np.all(np.abs(obs) <= 1)
+    rng = np.random.default_rng(0)
+    resets = 0
+    for _ in range(30):
+        actions = rng.integers(0, 13, n)
+        before = env._state.copy()
+        obs, rew, term, trunc, _ = env.step(actions)
+        assert obs.shape == (n, 4) and rew.shape == (n,) and term.shape == (n,) and trunc.shape == (n,)
+        assert not term.any()
+        assert np.all(np.abs(obs) <= 1)
+        done = term | trunc
+        resets += int(done.sum())
+        # envs that were not reset moved by the chosen step, clipped to [5, 10]
+        moved = np.clip(before[:, 1].astype(np.float64) + env._action_set[actions], 5, 10).astype(np.float32)
+        assert np.array_equal(env._state[~done, 1], moved[~done])
+        assert np.all(obs[done, 2:] == 0)  # reset observations carry zero deltas
+    assert resets > 0
+    env.close()
