@@ -413,7 +413,13 @@ double orc_var_u8(const uint8_t *src, long n)
         double d = (double)src[i] - mean;
         x[i] = d * d;
     }
-    double ret = pairwise_sum(x, n) / (double)n;
+    /* the reduction's inner loop runs over iterator chunks of at most 8192 elements
+     * (NPY_BUFSIZE), each summed pairwise and accumulated left to right -- checked
+     * empirically against numpy 1.26.4 and 2.2.6 for sizes up to 1024^2 */
+    double acc = 0.0;
+    for (long i = 0; i < n; i += 8192)
+        acc += pairwise_sum(x + i, (n - i) < 8192 ? (n - i) : 8192);
+    double ret = acc / (double)n;
     free(x);
     return ret;
 }

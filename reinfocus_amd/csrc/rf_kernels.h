@@ -55,10 +55,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
         const size_t pix = (size_t)e * a.hw + p;
 
         const ulonglong2 st = a.states[pix];
-        Rng g{st.x, st.y};
+        Rng g = rng_load(st.x, st.y);
         const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
         render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, env, a.cs, a.tab, cr, cg, cb);
-        a.states[pix] = make_ulonglong2(g.s0, g.s1);
+        a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
     }
 
     // uint8 truncation of float32(colour * scale)   (render.py:244-246)

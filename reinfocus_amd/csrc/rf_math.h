@@ -19,25 +19,66 @@
 #define RF_HD inline
 #endif
 
+// Value-preserving optimisation fence: stops hipcc from re-deriving a 32-bit word as
+// "high half of a 64-bit value" (it then expands u32->f32 as a generic u64->f32).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_OPAQUE32(x) asm("" : "+v"(x))
+#else
+#define RF_OPAQUE32(x) ((void)0)
+#endif
+
 namespace rf {
 
 // ---------------------------------------------------------------------------
 // xoroshiro128+ (numba.cuda.random xoroshiro128p_next; graphics/random.py:33)
+//
+// The state is kept as four 32-bit words and stepped with v_alignbit_b32 funnel
+// shifts: gfx950 runs 64-bit shifts (v_lshlrev_b64 / v_lshrrev_b64) at a fraction of
+// the 32-bit rate, and the RNG is ~60 % of the kernel's instructions.
 // ---------------------------------------------------------------------------
 struct Rng {
-    uint64_t s0, s1;
+    uint32_t a_lo, a_hi; // s0
+    uint32_t b_lo, b_hi; // s1
 };
 
-RF_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-
-RF_HD uint64_t rng_next(Rng &g)
+RF_HD Rng rng_load(uint64_t s0, uint64_t s1)
 {
-    uint64_t s0 = g.s0, s1 = g.s1;
-    uint64_t r = s0 + s1;
-    s1 ^= s0;
-    g.s0 = rotl64(s0, 55) ^ s1 ^ (s1 << 14);
-    g.s1 = rotl64(s1, 36);
-    return r;
+    return Rng{(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
+}
+RF_HD uint64_t rng_s0(const Rng &g) { return ((uint64_t)g.a_hi << 32) | g.a_lo; }
+RF_HD uint64_t rng_s1(const Rng &g) { return ((uint64_t)g.b_hi << 32) | g.b_lo; }
+
+// ({hi, lo} >> s)[31:0], s in [0, 31]  (v_alignbit_b32)
+RF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31));
+#endif
+}
+
+// result = s0 + s1 (as two words), then the xoroshiro128+ 55/14/36 state update:
+// one v_lshl_add_u64 for the sum, v_alignbit_b32 funnel shifts for everything else
+// (13 VALU instructions; checked in the ISA).
+RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
+{
+    const uint32_t a_lo = g.a_lo, a_hi = g.a_hi, b_lo = g.b_lo, b_hi = g.b_hi;
+    const uint64_t r = ((((uint64_t)a_hi) << 32) | a_lo) + ((((uint64_t)b_hi) << 32) | b_lo);
+    r_lo = (uint32_t)r;
+    r_hi = (uint32_t)(r >> 32);
+    RF_OPAQUE32(r_lo);
+    RF_OPAQUE32(r_hi);
+    const uint32_t x_lo = b_lo ^ a_lo, x_hi = b_hi ^ a_hi; // s1 ^= s0
+    // rotl(s0, 55) == rotr(s0, 9)
+    const uint32_t ro_lo = funnel_r(a_hi, a_lo, 9), ro_hi = funnel_r(a_lo, a_hi, 9);
+    // s1 << 14
+    const uint32_t sh_lo = x_lo << 14, sh_hi = funnel_r(x_hi, x_lo, 18);
+    g.a_lo = ro_lo ^ x_lo ^ sh_lo;
+    g.a_hi = ro_hi ^ x_hi ^ sh_hi;
+    // rotl(s1, 36) == rotl(swap halves, 4)
+    g.b_hi = funnel_r(x_lo, x_hi, 28);
+    g.b_lo = funnel_r(x_hi, x_lo, 28);
 }
 
 RF_HD int clz32(uint32_t x) { return x ? __builtin_clz(x) : 32; } // v_ffbh_u32
@@ -59,29 +100,67 @@ RF_HD float unit_f32_literal(uint64_t r)
     return (float)((double)(r >> 11) * (1.0 / 9007199254740992.0));
 }
 
-// Integer form, same value for every r: normalise the 53 kept bits, fold the bits
-// below the top 32 into a sticky bit (legal because a normalised 32-bit word keeps
+// General integer form, same value for every r: normalise the 53 kept bits, fold the
+// bits below the top 32 into a sticky bit (legal because a normalised 32-bit word keeps
 // its round bit at position >= 7), let v_cvt_f32_u32 do the single RNE, scale by an
 // exact power of two.
 RF_HD float unit_f32_int(uint64_t r)
 {
     uint32_t hi = (uint32_t)(r >> 32);
     uint32_t lo = (uint32_t)r & 0xFFFFF800u; // the 11 bits numba shifts out never count
-    int lz = hi ? clz32(hi) : 32;
+    int lz = clz32(hi);
     uint64_t y64 = (((uint64_t)hi << 32) | lo) << (lz & 63);
-    if (lz == 32)
-        y64 = (uint64_t)lo << 32;
     uint32_t y = (uint32_t)(y64 >> 32);
     uint32_t rest = (uint32_t)y64;
     y |= (rest != 0u) ? 1u : 0u;
     return ldexp_pow2((float)y, -32 - lz);
 }
 
+// Fast form: 2^48 * unit value, as ONE correctly rounded f32 (callers fold the exact
+// 2^-48 into their next fma).  The 53 kept bits are split into two exactly
+// representable floats, A = hi[31:8] * 2^16 and B = {hi[7:0], lo[31:16]} with
+// lo[15:11] OR-ed into B's low five bits, and a single fma adds them: fma rounds the
+// exact sum once, which is the RNE numba's f64->f32 cast performs.  OR-ing the tail
+// into B[4:0] only touches bits that are pure sticky bits when the result's last kept
+// bit is >= 6 positions above B's bit 0, i.e. when hi >= 2^13 (kFastHiMin); smaller
+// words (probability 2^-19) must take unit_f32_int.
+constexpr uint32_t kFastHiMin = 8192u;
+
+RF_HD float unit_f32_scaled48_fast(uint32_t r_hi, uint32_t r_lo) // requires r_hi >= kFastHiMin
+{
+    const float a = (float)(r_hi & 0xFFFFFF00u);                                   // exact: 24 bits
+    const uint32_t b = (funnel_r(r_hi, r_lo, 16) & 0x00FFFFFFu) | ((r_lo >> 11) & 31u);
+    return __builtin_fmaf(a, 65536.0f, (float)b);                                   // RN(A*2^16 + B)
+}
+
+RF_HD float unit_f32_scaled48_slow(uint32_t r_hi, uint32_t r_lo)
+{
+    return ldexp_pow2(unit_f32_int(((uint64_t)r_hi << 32) | r_lo), 48);
+}
+
+RF_HD float unit_f32_scaled48(uint32_t r_hi, uint32_t r_lo)
+{
+    if (__builtin_expect(r_hi < kFastHiMin, 0))
+        return unit_f32_scaled48_slow(r_hi, r_lo);
+    return unit_f32_scaled48_fast(r_hi, r_lo);
+}
+
+constexpr float kTwoM48 = 3.5527136788005009e-15f; // 2^-48
+constexpr float kTwoM47 = 7.1054273576010019e-15f; // 2^-47
+
+// 2^48 * xoroshiro128p_uniform_float32
+RF_HD float rng_uniform48(Rng &g)
+{
+    uint32_t hi, lo;
+    rng_next(g, hi, lo);
 #ifndef RF_UNIFORM_LITERAL
-RF_HD float rng_uniform(Rng &g) { return unit_f32_int(rng_next(g)); }
+    return unit_f32_scaled48(hi, lo);
 #else
-RF_HD float rng_uniform(Rng &g) { return unit_f32_literal(rng_next(g)); }
+    return ldexp_pow2(unit_f32_literal(((uint64_t)hi << 32) | lo), 48);
 #endif
+}
+
+RF_HD float rng_uniform(Rng &g) { return rng_uniform48(g) * kTwoM48; } // exact scaling
 
 // ---------------------------------------------------------------------------
 // scene parameters
@@ -150,32 +229,87 @@ struct Colour {
     float r, g, b;
 };
 
+// --- rejection loops ---------------------------------------------------------------
+// A rejected attempt only has to (a) advance the RNG state and (b) be rejected exactly
+// when the reference rejects it.  (b) is decided from a cheap approximation of the
+// candidate -- p~ = 2*RN24(r_hi)*2^-32 - 1, i.e. one v_cvt_f32_u32 and one fma per
+// coordinate instead of the exact 53-bit -> f32 conversion -- whenever the approximate
+// squared length is further than kAcceptBand from 1.  |p~ - p| <= 1.8e-7 per coordinate, so
+// the approximate and the reference's rounded squared lengths differ by < 1.5e-6 (three
+// coordinates, all roundings included); kAcceptBand = 2^-17 = 7.6e-6 leaves a 5x margin.
+// Inside the band (probability ~1e-5 per attempt) the exact expression decides.  The
+// accepted attempt is converted exactly after the loop, once.
+constexpr float kAcceptBand = 7.62939453125e-06f;  // 2^-17
+constexpr float kTwoM31 = 4.656612873077393e-10f; // 2^-31
+
+RF_HD float approx_pm1(uint32_t r_hi) { return __builtin_fmaf((float)r_hi, kTwoM31, -1.0f); }
+// == RN(xi*2f - 1f): the scalings by powers of two are exact
+RF_HD float exact_pm1(uint32_t r_hi, uint32_t r_lo)
+{
+    return __builtin_fmaf(unit_f32_scaled48(r_hi, r_lo), kTwoM47, -1.0f);
+}
+RF_HD float exact_pm1_fast(uint32_t r_hi, uint32_t r_lo)
+{
+    return __builtin_fmaf(unit_f32_scaled48_fast(r_hi, r_lo), kTwoM47, -1.0f);
+}
+RF_HD float exact_pm1_slow(uint32_t r_hi, uint32_t r_lo)
+{
+    return __builtin_fmaf(unit_f32_scaled48_slow(r_hi, r_lo), kTwoM47, -1.0f);
+}
+
 RF_HD void disc_sample(Rng &g, float &p0, float &p1)
 {
-    // camera.py:229-252.  a*2f is exact, so fma(a, 2, -1) == RN(a*2f - 1f).
+    // camera.py:229-252: accept when p0*p0 + p1*p1 < 1 (f32 products, f32 sum)
+    uint32_t ah, al, bh, bl;
     for (;;) {
-        float a = rng_uniform(g);
-        float b = rng_uniform(g);
-        p0 = __builtin_fmaf(a, 2.0f, -1.0f);
-        p1 = __builtin_fmaf(b, 2.0f, -1.0f);
-        float d0 = p0 * p0, d1 = p1 * p1;
-        if (d0 + d1 < 1.0f)
-            return;
+        rng_next(g, ah, al);
+        rng_next(g, bh, bl);
+        const float ta = approx_pm1(ah), tb = approx_pm1(bh);
+        const float sq = __builtin_fmaf(ta, ta, tb * tb);
+        bool accept = sq < 1.0f - kAcceptBand;
+        if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0)) {
+            const float e0 = exact_pm1(ah, al), e1 = exact_pm1(bh, bl);
+            const float d0 = e0 * e0, d1 = e1 * e1;
+            accept = d0 + d1 < 1.0f;
+        }
+        if (accept)
+            break;
+    }
+    if (__builtin_expect((ah < bh ? ah : bh) < kFastHiMin, 0)) {
+        p0 = exact_pm1_slow(ah, al);
+        p1 = exact_pm1_slow(bh, bl);
+    } else {
+        p0 = exact_pm1_fast(ah, al);
+        p1 = exact_pm1_fast(bh, bl);
     }
 }
 
 RF_HD void sphere_sample(Rng &g, float &q0, float &q1, float &q2)
 {
-    // physics.py:20-44
+    // physics.py:20-44: accept when float32(q0**2) + float32(q1**2) + float32(q2**2) < 1
+    uint32_t ah, al, bh, bl, ch, cl;
     for (;;) {
-        float a = rng_uniform(g);
-        float b = rng_uniform(g);
-        float c = rng_uniform(g);
-        q0 = __builtin_fmaf(a, 2.0f, -1.0f);
-        q1 = __builtin_fmaf(b, 2.0f, -1.0f);
-        q2 = __builtin_fmaf(c, 2.0f, -1.0f);
-        if (sq_len(q0, q1, q2) < 1.0f)
-            return;
+        rng_next(g, ah, al);
+        rng_next(g, bh, bl);
+        rng_next(g, ch, cl);
+        const float ta = approx_pm1(ah), tb = approx_pm1(bh), tc = approx_pm1(ch);
+        const float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
+        bool accept = sq < 1.0f - kAcceptBand;
+        if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0))
+            accept = sq_len(exact_pm1(ah, al), exact_pm1(bh, bl), exact_pm1(ch, cl)) < 1.0f;
+        if (accept)
+            break;
+    }
+    uint32_t lowest = ah < bh ? ah : bh;
+    lowest = lowest < ch ? lowest : ch;
+    if (__builtin_expect(lowest < kFastHiMin, 0)) {
+        q0 = exact_pm1_slow(ah, al);
+        q1 = exact_pm1_slow(bh, bl);
+        q2 = exact_pm1_slow(ch, cl);
+    } else {
+        q0 = exact_pm1_fast(ah, al);
+        q1 = exact_pm1_fast(bh, bl);
+        q2 = exact_pm1_fast(ch, cl);
     }
 }
 
@@ -261,6 +395,11 @@ RF_HD float pixel_coord_pow2(int x, float xi, float inv_w)
 {
     return ((float)x + xi) * inv_w;
 }
+// same with xi48 = 2^48 * xi: fma(xi48, 2^-48, x) == RN(x + xi)
+RF_HD float pixel_coord_pow2_48(float xf, float xi48, float inv_w)
+{
+    return __builtin_fmaf(xi48, kTwoM48, xf) * inv_w;
+}
 
 // ---------------------------------------------------------------------------
 // one pixel of FastRenderer._device_render (render.py:210-246): spp samples
@@ -342,11 +481,12 @@ RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w
                         float &cg, float &cb)
 {
     cr = cg = cb = 0.0f;
+    const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
-        float xi = rng_uniform(g);
-        float s = POW2 ? pixel_coord_pow2(x, xi, inv_w) : pixel_coord_literal(x, xi, w);
-        float yi = rng_uniform(g);
-        float t = POW2 ? pixel_coord_pow2(y, yi, inv_h) : pixel_coord_literal(y, yi, h);
+        float xi = rng_uniform48(g);
+        float s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_literal(x, xi * kTwoM48, w);
+        float yi = rng_uniform48(g);
+        float t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_literal(y, yi * kTwoM48, h);
         Colour c = AXIS ? sample_axis(g, e, cs.lens_radius, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);
         cr = add2(cr, c.r);

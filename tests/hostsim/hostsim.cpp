@@ -39,7 +39,7 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
                 const long pix = ((long)e * h + y) * w + x;
-                Rng g{states[2 * pix], states[2 * pix + 1]};
+                Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
                 float cr, cg, cb;
                 switch (mode & 3) {
                 case 3: render_pixel<true, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
@@ -47,8 +47,8 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
                 case 2: render_pixel<false, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
                 default: render_pixel<false, false>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
                 }
-                states[2 * pix] = g.s0;
-                states[2 * pix + 1] = g.s1;
+                states[2 * pix] = rng_s0(g);
+                states[2 * pix + 1] = rng_s1(g);
                 frames[pix * 3 + 0] = (uint8_t)(cr * scale);
                 frames[pix * 3 + 1] = (uint8_t)(cg * scale);
                 frames[pix * 3 + 2] = (uint8_t)(cb * scale);
@@ -64,7 +64,8 @@ long hs_check_uniform(const uint64_t *words, long n)
     for (long i = 0; i < n; ++i) {
         float a = unit_f32_int(words[i]);
         float b = unit_f32_literal(words[i]);
-        if (!(a == b))
+        float c = unit_f32_scaled48((uint32_t)(words[i] >> 32), (uint32_t)words[i]) * kTwoM48;
+        if (!(a == b) || !(c == b))
             ++bad;
     }
     return bad;
@@ -95,6 +96,49 @@ long hs_check_checker(const float *us, const float *vs, long n)
         if (lit != fast)
             ++bad;
     }
+    return bad;
+}
+
+// The rejection loops' fast accept decision (approximate test + exact band) against
+// the literal one, for caller-supplied 64-bit draw words.  dims = 2 (disc) or 3 (sphere).
+// words: n * dims u64.  Returns mismatches; *in_band counts how often the band path ran.
+long hs_check_accept(const uint64_t *words, long n, int dims, long *in_band)
+{
+    long bad = 0, band = 0;
+    for (long i = 0; i < n; ++i) {
+        float lit[3] = {0, 0, 0}, apx[3] = {0, 0, 0};
+        for (int k = 0; k < dims; ++k) {
+            const uint64_t w = words[i * dims + k];
+            lit[k] = unit_f32_literal(w) * 2.0f - 1.0f;
+            apx[k] = approx_pm1((uint32_t)(w >> 32));
+        }
+        bool want, got;
+        float sq;
+        if (dims == 2) {
+            const float d0 = lit[0] * lit[0], d1 = lit[1] * lit[1];
+            want = (double)(d0 + d1) < 1.0;
+            sq = __builtin_fmaf(apx[0], apx[0], apx[1] * apx[1]);
+        } else {
+            want = (double)sq_len(lit[0], lit[1], lit[2]) < 1.0;
+            sq = __builtin_fmaf(apx[0], apx[0], __builtin_fmaf(apx[1], apx[1], apx[2] * apx[2]));
+        }
+        got = sq < 1.0f - kAcceptBand;
+        if (!got && sq < 1.0f + kAcceptBand) {
+            ++band;
+            float e[3] = {0, 0, 0};
+            for (int k = 0; k < dims; ++k)
+                e[k] = exact_pm1((uint32_t)(words[i * dims + k] >> 32), (uint32_t)words[i * dims + k]);
+            if (dims == 2) {
+                const float d0 = e[0] * e[0], d1 = e[1] * e[1];
+                got = d0 + d1 < 1.0f;
+            } else {
+                got = sq_len(e[0], e[1], e[2]) < 1.0f;
+            }
+        }
+        if (got != want)
+            ++bad;
+    }
+    *in_band = band;
     return bad;
 }
 

@@ -1,0 +1,266 @@
+"""Every known answer the reference's own tests hold for the hot path (SURVEY.md section
+8(c)), asserted against the oracle and the host logic.  The tests read like the
+reference's (tests/graphics/*_test.py, tests/vision_test.py) with the numba wrapper
+kernels replaced by direct calls of the oracle's device functions.  The last test pins
+the oracle to real outputs of the reference itself (examples/environment.ipynb)."""
+
+import numpy as np
+from numpy import testing
+
+from tests import helpers
+
+
+# --- tests/graphics/camera_test.py -----------------------------------------------------------
+
+
+def test_fast_cameras_device_data():
+    """camera_test.py:65-80."""
+    from reinfocus_amd.graphics import camera
+
+    testee = camera.FastCameras()
+    testee.update([10])
+    dyn, origin, u, v, lens = testee.device_data()
+    testing.assert_allclose(dyn[0], [[-2.68, -2.68, -10], [5.36, 0, 0], [0, 5.36, 0]], atol=0.01)
+    testing.assert_allclose(origin, [0, 0, 0])
+    testing.assert_allclose(u, [1, 0, 0])
+    testing.assert_allclose(v, [0, 1, 0])
+    assert lens == 0.05
+    # camera_test.py:82-112: the unpacked 19-vector
+    flat = np.concatenate([dyn[0].ravel(), origin, u, v, [lens]])
+    testing.assert_allclose(
+        flat, [-2.68, -2.68, -10, 5.36, 0, 0, 0, 5.36, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0.05], atol=0.01)
+
+
+def test_random_in_unit_disc(oracle):
+    """camera_test.py:145-167: 100 states, seed 0."""
+    states = oracle.seed_states(100, 0)
+    pts = np.array([oracle.random_in_unit_disc(states[i]) for i in range(100)])
+    assert np.all(np.linalg.norm(pts, axis=-1) < 1.0)
+
+
+def test_get_ray_middle_pixel(oracle):
+    """camera_test.py:170-197: make_gpu_camera(look_at=(0,0,-1)) has the same frame and
+    focus distance 10 as FastCameras().update([10])."""
+    dyn, _, origin, u, v, lens = helpers.pack_scene([10], [10])
+    state = oracle.seed_states(1, 0)[0]
+    o, d = oracle.get_ray(dyn[0], oracle.cam_static(origin, u, v, lens), 0.5, 0.5, state)
+    assert np.all(np.abs(np.concatenate([o, d[:2]])) < 0.1)
+    assert abs(d[2] - (-10)) < 1e-6
+
+
+# --- tests/graphics/world_test.py -------------------------------------------------------------
+
+
+def test_fast_world_parameters():
+    """world_test.py:105-127."""
+    from reinfocus_amd.graphics import world
+
+    testee = world.FastWorlds()
+    testee.update([1, 2, 3])
+    sizes = testee.device_data()[:, 0].copy()
+    testing.assert_allclose(testee.device_data()[:, 1], [-1, -2, -3])
+    testing.assert_array_less(0, sizes)
+    testee.update([3, 2, 1])
+    reversed_sizes = testee.device_data()[:, 0]
+    testing.assert_allclose(testee.device_data()[:, 1], [-3, -2, -1])
+    testing.assert_array_less(0, reversed_sizes)
+    testing.assert_allclose(sizes, list(reversed(reversed_sizes)))
+
+
+# --- tests/graphics/rectangle_test.py ----------------------------------------------------------
+
+
+def test_uv(oracle):
+    """rectangle_test.py:103-134: five exact answers."""
+    pts = [(-1, -1), (-1, 1), (1, -1), (1, 1), (0, 0)]
+    got = np.array([oracle.uv(p, -1, 1, -1, 1) for p in pts])
+    testing.assert_allclose(got, [[0, 0], [0, 1], [1, 0], [1, 1], [0.5, 0.5]])
+
+
+def test_fast_hit(oracle):
+    """rectangle_test.py:69-100 (a smoke test there) + the exact record of :35-66 shape."""
+    from reinfocus_amd.graphics import world
+
+    data = world.FastWorlds(1)
+    data.update([1])
+    hit, rec = oracle.fast_hit(data.device_data()[0], (0, 0, 0), (0, 0, -1), 0.0, 100.0)
+    assert hit
+    # p, n, t, uv, uf, m
+    testing.assert_allclose(rec[:12], (0, 0, -1, 0, 0, 1, 1, 0.5, 0.5, 32, 32, 1))
+    miss, _ = oracle.fast_hit(data.device_data()[0], (0, 0, 0), (0, 0, 1), 0.0, 100.0)
+    assert not miss
+    edge, _ = oracle.fast_hit(np.array([1.0, -1.0], dtype=np.float32), (1, 1, 0), (0, 0, -1), 0.0, 100.0)
+    assert edge  # edges count as hits (strict comparisons, rectangle.py:135)
+
+
+# --- tests/graphics/physics_test.py ------------------------------------------------------------
+
+
+def test_random_in_unit_sphere(oracle):
+    """physics_test.py:24-46."""
+    states = oracle.seed_states(100, 0)
+    pts = np.array([oracle.random_in_unit_sphere(states[i]) for i in range(100)])
+    assert np.all(np.linalg.norm(pts, axis=-1) < 1.0)
+
+
+def test_known_checkerboards(oracle):
+    """physics_test.py:49-97: eight exact colours."""
+    cases = [((1, 1), (0.25, 0.25)), ((1, 1), (0.25, 0.75)), ((1, 1), (0.75, 0.25)), ((1, 1), (0.75, 0.75)),
+             ((2, 2), (0.25, 0.25)), ((2, 2), (0.25, 0.75)), ((2, 2), (0.75, 0.25)), ((2, 2), (0.75, 0.75))]
+    got = np.array([oracle.colour_checkerboard(f, p) for f, p in cases])
+    testing.assert_allclose(got, [[1, 0, 0]] * 5 + [[0, 1, 0]] * 2 + [[1, 0, 0]])
+
+
+def test_scatter_rectangle(oracle):
+    """physics_test.py:100-139."""
+    rec = np.array([0, 0, 0, 0, 0, 1, 1.0, 2**-4, 2**-4, 1.0, 1.0, 1.0, 0], dtype=np.float32)
+    state = oracle.seed_states(1, 0)[0]
+    o, d, att = oracle.scatter(rec, state)
+    testing.assert_allclose(o, [0, 0, 0])
+    assert np.linalg.norm(d - np.array([0, 0, 1])) < 1.0
+    testing.assert_allclose(att, [1, 0, 0])
+
+
+def test_fast_find_colour(oracle):
+    """physics_test.py:249-284."""
+    from reinfocus_amd.graphics import world
+
+    data = world.FastWorlds()
+    data.update([1])
+    state = oracle.seed_states(1, 0)[0]
+    col = oracle.fast_find_colour(data.device_data()[0], (-(2**-4), -(2**-4), 0), (-(2**-4), -(2**-4), -1), state)
+    assert 0 < col[0] <= 1.0
+    testing.assert_allclose(col[1:3], [0, 0])
+
+
+# --- tests/graphics/random_test.py --------------------------------------------------------------
+
+
+def test_make_random_states_and_uniform_range(oracle):
+    """random_test.py:13-46."""
+    states = oracle.seed_states(10, 0)
+    assert len(states) == 10
+    states = oracle.seed_states(100, 0)
+    draws = np.array([oracle.uniform_float(states[i]) for i in range(100)])
+    assert np.all((0.0 <= draws) & (draws < 1.0))
+
+
+# --- tests/graphics/render_test.py ---------------------------------------------------------------
+
+
+def test_fast_renderer_average_colour(oracle):
+    """render_test.py:86-98: r_size 30, target = focus = 10, 300 px, 100 spp: every ray
+    hits, so mean B is exactly 0 and mean R, G lie in [63.75, 127.5]."""
+    dyn, rect, origin, u, v, lens = helpers.pack_scene([10], [10], r_size=30)
+    st = oracle.seed_states(300 * 300, 0)
+    frames = oracle.render(dyn, rect, 300, 300, 100, st, n_threads=8)
+    avg = np.average(frames, axis=(0, 1, 2))
+    assert np.all(avg >= np.multiply([0.25, 0.25, 0], 255))
+    assert np.all(avg <= np.multiply([0.5, 0.5, 0], 255))
+
+
+# --- tests/vision_test.py --------------------------------------------------------------------------
+
+
+def test_vision_known_answers(oracle):
+    """vision_test.py:14-34."""
+    assert oracle.focus_value(np.zeros((10, 10, 3), dtype=np.uint8)) == 0
+    assert oracle.focus_value(np.ones((10, 10, 3), dtype=np.uint8)) == 0
+    frame = np.zeros((10, 10, 3), dtype=np.uint8)
+    frame[0:10:2, :, :] = 255
+    frame[:, 0:10:2, :] = 255 - frame[:, 0:10:2, :]
+    assert oracle.focus_value(frame) > 1
+
+
+def test_ray_traced_focus_ordering(oracle):
+    """vision_test.py:40-56: targets all 10, focus planes [40, 20, 10, 5, 1]."""
+    dyn, rect, origin, u, v, lens = helpers.pack_scene([10] * 5, [40, 20, 10, 5, 1])
+    st = oracle.seed_states(5 * 300 * 300, 0)
+    fv = oracle.focus_values(oracle.render(dyn, rect, 300, 300, 100, st, n_threads=8), n_threads=8)
+    assert fv[2] > fv[3] > fv[4]
+    assert fv[2] > fv[1] > fv[0]
+
+
+# --- tests/graphics/device_data_test.py ---------------------------------------------------------------
+
+
+def test_device_data_cache_semantics():
+    """device_data_test.py:28-69 (the reference mocks _make_device_data; here a counter)."""
+    from reinfocus_amd.graphics import device_data
+
+    class Counting(device_data.DeviceData):
+        calls = 0
+
+        def _make_device_data(self, data):
+            Counting.calls += 1
+            return data * 2
+
+    testee = Counting()
+    assert len(testee) == 0
+    try:
+        testee.device_data()
+        raise RuntimeError("device_data() before update() must assert")
+    except AssertionError:
+        pass
+    testee.update([1, 2, 3])
+    assert Counting.calls == 1 and len(testee) == 3
+    testee.update([1, 2, 3])            # unchanged: no re-pack
+    assert Counting.calls == 1
+    testee.update([1, 2, 4])            # value change
+    assert Counting.calls == 2
+    testee.update([1, 2, 4, 5])         # shape change
+    assert Counting.calls == 3 and len(testee) == 4
+    testing.assert_allclose(testee.device_data(), [2, 4, 8, 10])
+    testee.update([np.nan])
+    testee.update([np.nan])             # NaN != NaN: re-packs, as the reference's all(==)
+    assert Counting.calls == 5
+
+
+# --- examples/environment.ipynb: outputs of the real reference ------------------------------------------
+
+
+def test_oracle_reproduces_reference_notebook(oracle):
+    """examples/environment.ipynb holds outputs the reference itself produced (numba on
+    CUDA, OpenCV 4.9): reset -> obs[1] = -0.84483975 at state (5.311405, 8.66759); after a
+    600 px visualiser render and action 8 -> obs = [0.59203607, -0.873161, 0.0625,
+    -0.01416067].  Replaying the same call sequence on the oracle (seed-0 states, 13-env
+    extrema render, 300 px / 100 spp, 600 px re-seed, 15-bit gray) prints the same digits."""
+    f32 = np.float32
+
+    def render_focus(targets, focus, height, states):
+        dyn, rect, o, u, v, lens = helpers.pack_scene(targets, focus)
+        frames = oracle.render(dyn, rect, height, height, 100, states, n_threads=8)
+        return oracle.focus_values(frames, 15, n_threads=8)
+
+    # state_observer.py:295-320 cached_focus_extrema((5.0, 10.0), 300), fresh seed-0 states
+    ends = (5.0, 10.0)
+    mids = np.linspace(*ends, 11)
+    fv = render_focus(np.append(ends, mids), np.append(ends[::-1], mids), 300, oracle.seed_states(13 * 300 * 300, 0))
+    min_focus, max_focus = min(fv[0:2]), max(fv[2:13])
+    # NormalizedObserver(DeltaObserver(...)) spans, all float32 (state_observer.py:166-230, :440-470)
+    lows, highs = np.array([5, min_focus], dtype=f32), np.array([10, max_focus], dtype=f32)
+    diff = highs - lows
+    diff[0] = 5.0
+    spans = np.vstack([np.append(lows, -diff), np.append(highs, diff)]).astype(f32)
+    mid, scale = np.average(spans, axis=0), np.diff(spans / 2, axis=0).reshape(4)
+
+    def normalize(values):
+        return np.clip((np.asarray(values, dtype=f32) - mid) / scale, -1, 1, dtype=f32)
+
+    target, focus0, focus1 = f32(5.311405), f32(8.66759), f32(8.98009)
+    assert f32(np.float64(focus0) + 0.3125) == focus1  # action 8 = +0.3125
+
+    states = oracle.seed_states(300 * 300, 0)           # env renderer: fresh seed-0 states
+    fv0 = render_focus([target], [focus0], 300, states)[0]
+    obs0 = normalize([focus0, fv0, 0, 0])
+    assert repr(obs0) == "array([ 0.46703607, -0.84483975,  0.        ,  0.        ], dtype=float32)"
+
+    states = oracle.seed_states(600 * 600, 0)           # visualize(): render(600) re-seeds (render.py:256)
+    render_focus([target], [focus0], 600, states)
+    fv1 = render_focus([target], [focus1], 300, states)[0]
+    wrapped0 = np.array([focus0, fv0], dtype=f32)
+    wrapped1 = np.array([focus1, fv1], dtype=f32)
+    obs1 = normalize(np.concatenate([wrapped1, wrapped1 - wrapped0]))
+    assert repr(obs1) == "array([ 0.59203607, -0.873161  ,  0.0625    , -0.01416067], dtype=float32)"
+    reward = (abs(focus1 - focus0) * -1.0 / 0.5 + obs1[1]) + ((abs(target - focus1) < 0.25) * 1.0 + 0.0)
+    assert reward == -1.4981610774993896
