@@ -9,13 +9,17 @@
  * no FMA contraction (what NUMBA_ENABLE_CUDASIM=1 computes).  Build with
  *   gcc -O2 -ffp-contract=off -fno-fast-math
  *
- * Parity status: the reference itself cannot be executed in this image
- * (numba / cv2 / gymnasium absent), so this oracle is pinned by (i) every
- * known answer the reference's own tests hold for the path, (ii) an
- * independent numpy-1.26.4 restatement (oracle/np126_restatement.py ->
- * tests/golden), (iii) scipy.ndimage for the vision stages.  The third-party
- * arithmetic (numba xoroshiro128+, OpenCV 4.9 gray/median/Laplacian) is
- * restated from their published algorithms: that part is "parity unpinned".
+ * Parity status: PINNED.  The reference cannot be imported in this image (numba / cv2 /
+ * gymnasium absent), but its repository holds real outputs of itself: the cells of
+ * examples/environment.ipynb (numba on CUDA + OpenCV 4.9).  Replaying that call sequence on
+ * this oracle reproduces every printed digit (tests/test_reference_known_answers.py::
+ * test_oracle_reproduces_reference_notebook), which exercises seeding, four renders, the
+ * OpenCV chain and var().  In addition: (i) every known answer the reference's own tests
+ * hold for the path, (ii) an independent numpy-1.26.4 restatement
+ * (oracle/np126_restatement.py -> tests/golden), (iii) scipy.ndimage and numpy for the
+ * vision stages.  Third-party arithmetic (numba xoroshiro128+, OpenCV gray / median /
+ * Laplacian) is restated from the published algorithms and confirmed only through (the
+ * strong) notebook check above.
  */
 #ifndef RF_ORACLE_H
 #define RF_ORACLE_H

@@ -1,0 +1,65 @@
+"""The C-ABI shared library: it loads, exports every symbol include/reinfocus_hip.h
+declares, and fails loudly (no CPU fallback) when no GPU is present.  No compute calls."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "reinfocus_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding():
+    from reinfocus_amd import _native
+
+    declared = _declared_symbols()
+    assert declared, "no rf_* declarations found in include/reinfocus_hip.h"
+    assert sorted(_native.SYMBOLS) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    from reinfocus_amd import _native
+
+    assert os.path.exists(_native.LIB_PATH), "build with __graft_entry__.build() first"
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in the header but not exported"
+    assert _native.load().rf_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    """On a host without a GPU the product path must raise, not fall back."""
+    from reinfocus_amd import _native
+
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        _native.Context(0)
+    from reinfocus_amd.graphics import render
+
+    with pytest.raises(RuntimeError):
+        render.FastRenderer()
+    from reinfocus_amd import vision
+    import numpy as np
+
+    with pytest.raises(RuntimeError):
+        vision.focus_value(np.zeros((4, 4, 3), dtype=np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "reinfocus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+                assert "librf_oracle" not in text and "rf_oracle.h" not in text, os.path.join(dirpath, f)
+                assert "hostsim" not in text or f == "rf_math.h", os.path.join(dirpath, f)

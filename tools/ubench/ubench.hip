@@ -72,6 +72,27 @@ KERNEL32(k_div_fixup, "v_div_fixup_f32 %0, %0, %5, %5\nv_div_fixup_f32 %1, %1, %
 KERNEL32(k_perm, "v_perm_b32 %0, %0, %4, %5\nv_perm_b32 %1, %1, %4, %5\nv_perm_b32 %2, %2, %4, %5\nv_perm_b32 %3, %3, %4, %5\n")
 KERNEL32(k_mix_xor_fma, "v_xor_b32 %0, %0, %4\nv_fma_f32 %1, %1, %5, %5\nv_xor_b32 %2, %2, %4\nv_fma_f32 %3, %3, %5, %5\n")
 KERNEL32(k_mix_xor_alignbit, "v_xor_b32 %0, %0, %4\nv_alignbit_b32 %1, %1, %4, 9\nv_xor_b32 %2, %2, %4\nv_alignbit_b32 %3, %3, %4, 9\n")
+
+KERNEL32(k_and, "v_and_b32 %0, %0, %4\nv_and_b32 %1, %1, %4\nv_and_b32 %2, %2, %4\nv_and_b32 %3, %3, %4\n")
+KERNEL32(k_or, "v_or_b32 %0, %0, %4\nv_or_b32 %1, %1, %4\nv_or_b32 %2, %2, %4\nv_or_b32 %3, %3, %4\n")
+KERNEL32(k_sub_u32, "v_sub_u32 %0, %0, %4\nv_sub_u32 %1, %1, %4\nv_sub_u32 %2, %2, %4\nv_sub_u32 %3, %3, %4\n")
+KERNEL32(k_mov, "v_mov_b32 %0, %4\nv_mov_b32 %1, %4\nv_mov_b32 %2, %4\nv_mov_b32 %3, %4\n")
+KERNEL32(k_fmac, "v_fmac_f32 %0, %5, %5\nv_fmac_f32 %1, %5, %5\nv_fmac_f32 %2, %5, %5\nv_fmac_f32 %3, %5, %5\n")
+KERNEL32(k_fma_distinct, "v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n")
+KERNEL32(k_mul_u24, "v_mul_u32_u24 %0, %0, %4\nv_mul_u32_u24 %1, %1, %4\nv_mul_u32_u24 %2, %2, %4\nv_mul_u32_u24 %3, %3, %4\n")
+KERNEL32(k_mad_u24, "v_mad_u32_u24 %0, %0, %4, %5\nv_mad_u32_u24 %1, %1, %4, %5\nv_mad_u32_u24 %2, %2, %4, %5\nv_mad_u32_u24 %3, %3, %4, %5\n")
+KERNEL32(k_mul_lo, "v_mul_lo_u32 %0, %0, %4\nv_mul_lo_u32 %1, %1, %4\nv_mul_lo_u32 %2, %2, %4\nv_mul_lo_u32 %3, %3, %4\n")
+KERNEL32(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %4\nv_lshl_or_b32 %1, %1, 3, %4\nv_lshl_or_b32 %2, %2, 3, %4\nv_lshl_or_b32 %3, %3, 3, %4\n")
+KERNEL32(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %4\nv_lshl_add_u32 %1, %1, 3, %4\nv_lshl_add_u32 %2, %2, 3, %4\nv_lshl_add_u32 %3, %3, 3, %4\n")
+KERNEL32(k_add3, "v_add3_u32 %0, %0, %4, %5\nv_add3_u32 %1, %1, %4, %5\nv_add3_u32 %2, %2, %4, %5\nv_add3_u32 %3, %3, %4, %5\n")
+KERNEL32(k_bfi, "v_bfi_b32 %0, %0, %4, %5\nv_bfi_b32 %1, %1, %4, %5\nv_bfi_b32 %2, %2, %4, %5\nv_bfi_b32 %3, %3, %4, %5\n")
+KERNEL32(k_max_f32, "v_max_f32 %0, %0, %5\nv_max_f32 %1, %1, %5\nv_max_f32 %2, %2, %5\nv_max_f32 %3, %3, %5\n")
+KERNEL32(k_max_u32, "v_max_u32 %0, %0, %4\nv_max_u32 %1, %1, %4\nv_max_u32 %2, %2, %4\nv_max_u32 %3, %3, %4\n")
+KERNEL32(k_sub_f32, "v_sub_f32 %0, %0, %5\nv_sub_f32 %1, %1, %5\nv_sub_f32 %2, %2, %5\nv_sub_f32 %3, %3, %5\n")
+KERNEL32(k_lshr, "v_lshrrev_b32 %0, 9, %0\nv_lshrrev_b32 %1, 9, %1\nv_lshrrev_b32 %2, 9, %2\nv_lshrrev_b32 %3, 9, %3\n")
+KERNEL32(k_cmp_only, "v_cmp_lt_u32 vcc, %0, %4\nv_cmp_lt_u32 vcc, %1, %4\nv_cmp_lt_u32 vcc, %2, %4\nv_cmp_lt_u32 vcc, %3, %4\n")
+KERNEL32(k_xor_chain1, "v_xor_b32 %0, %0, %4\nv_xor_b32 %0, %0, %5\nv_xor_b32 %0, %0, %4\nv_xor_b32 %0, %0, %5\n")
+KERNEL32(k_alignbit_chain1, "v_alignbit_b32 %0, %0, %4, 9\nv_alignbit_b32 %0, %0, %4, 9\nv_alignbit_b32 %0, %0, %4, 9\nv_alignbit_b32 %0, %0, %4, 9\n")
 KERNEL64(k_lshl_b64, "v_lshlrev_b64 %0, 14, %0\nv_lshlrev_b64 %1, 14, %1\nv_lshlrev_b64 %2, 14, %2\nv_lshlrev_b64 %3, 14, %3\n")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %4\nv_lshl_add_u64 %1, %1, 0, %4\nv_lshl_add_u64 %2, %2, 0, %4\nv_lshl_add_u64 %3, %3, 0, %4\n")
 KERNEL64(k_mul_f64, "v_mul_f64 %0, %0, %4\nv_mul_f64 %1, %1, %4\nv_mul_f64 %2, %2, %4\nv_mul_f64 %3, %3, %4\n")
@@ -120,6 +141,11 @@ int main()
         {"v_cmp+v_cndmask", k_cmp_cnd}, {"v_ffbh_u32", k_ffbh}, {"v_bfe_u32", k_bfe}, {"v_min_u32", k_min_u32},
         {"v_rcp_f32", k_rcp_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_floor_f32", k_floor_f32}, {"v_cvt_i32_f32", k_cvt_i32_f32},
         {"v_div_scale_f32", k_div_scale}, {"v_div_fixup_f32", k_div_fixup}, {"v_perm_b32", k_perm},
+        {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_sub_u32", k_sub_u32}, {"v_mov_b32", k_mov}, {"v_fmac_f32", k_fmac},
+        {"v_fma_f32 (3 regs)", k_fma_distinct}, {"v_mul_u32_u24", k_mul_u24}, {"v_mad_u32_u24", k_mad_u24}, {"v_mul_lo_u32", k_mul_lo},
+        {"v_lshl_or_b32", k_lshl_or}, {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_bfi_b32", k_bfi},
+        {"v_max_f32", k_max_f32}, {"v_max_u32", k_max_u32}, {"v_sub_f32", k_sub_f32}, {"v_lshrrev_b32", k_lshr}, {"v_cmp_lt_u32", k_cmp_only},
+        {"xor 1 chain", k_xor_chain1}, {"alignbit 1 chain", k_alignbit_chain1},
         {"mix xor+fma", k_mix_xor_fma}, {"mix xor+alignbit", k_mix_xor_alignbit},
         {"v_lshlrev_b64", k_lshl_b64}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_mul_f64", k_mul_f64}, {"v_fma_f64", k_fma_f64},
         {"v_add_f64", k_add_f64}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
