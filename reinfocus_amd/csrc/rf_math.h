@@ -210,6 +210,17 @@ RF_HD int checker_sign(float u, const CheckerTable &tab)
     return neg ? -1 : 1;
 }
 
+// sin(32 pi u) * sin(32 pi v) > 0 for u, v >= 0: the common case (neither 32u nor 32v an
+// integer) is one parity test of trunc(32u) ^ trunc(32v); exact integers take the table.
+RF_HD bool checker_red(float u, float v, const CheckerTable &tab)
+{
+    const float mu = u * 32.0f, mv = v * 32.0f;
+    const int ku = (int)mu, kv = (int)mv; // trunc == floor: u, v >= 0
+    if (__builtin_expect(mu == (float)ku || mv == (float)kv, 0))
+        return (checker_sign(u, tab) * checker_sign(v, tab)) > 0;
+    return ((ku ^ kv) & 1) == 0;
+}
+
 // ---------------------------------------------------------------------------
 // one sample: camera.get_ray (camera.py:307-350) + physics.fast_find_colour
 // (physics.py:148-193) with rectangle.fast_hit (rectangle.py:102-148).
@@ -314,8 +325,9 @@ RF_HD void sphere_sample(Rng &g, float &q0, float &q1, float &q2)
 }
 
 // physics.py:183-193: sky colour of direction d times attenuation.
-// T = 0.5*(ud.y + 1.0) in f64; 0.5*x is exact so T == fma(ud.y, 0.5, 0.5).
-RF_HD double sky_t(float d0, float d1, float d2)
+// Literal form: T = 0.5*(ud.y + 1.0) in f64 (0.5*x is exact so T == fma(ud.y, 0.5, 0.5)),
+// white = f32(1 - T), blue_k = f32(f64(k) * T), channel = white + blue_k.
+RF_HD float unit_dir_y(float d0, float d1, float d2)
 {
     float sq = sq_len(d0, d1, d2);
     // float32(math.sqrt(sq)): an f64 sqrt rounded to f32 equals the correctly rounded
@@ -323,15 +335,28 @@ RF_HD double sky_t(float d0, float d1, float d2)
     // default; __fsqrt_rn would be the *native* 1-ulp sqrt).
     float len = __builtin_sqrtf(sq);
     float inv = 1.0f / len;
-    float ud1 = d1 * inv;
-    return __builtin_fma((double)ud1, 0.5, 0.5);
+    return d1 * inv;
 }
 
-RF_HD float sky_channel(double t, float white, float k)
+RF_HD double sky_t(float ud1) { return __builtin_fma((double)ud1, 0.5, 0.5); }
+
+RF_HD float sky_channel_literal(double t, float white, float k)
 {
     float blue = (float)((double)k * t);
     return add2(white, blue);
 }
+
+// f32 form of the same values.  With ud = ud.y (|ud| <= 1 + few ulp):
+//   T exact = 0.5 + 0.5*ud has <= 26 significant bits, so the f64 operations of the
+//   literal form are exact (for |ud| < 2^-29 they round, but by < 2^-53, far below the
+//   f32 half-ulp of the results), k*T_exact has <= 50 bits (exact in f64), and therefore
+//   f32(1 - T) == fma(-0.5, ud, 0.5) and f32(k*T) == fma(k/2, ud, k/2): one rounding of the
+//   same exact value.  k/2 is exact for every f32 k.  Checked for every f32 ud in
+//   [-1-8ulp, 1+8ulp] by tests/test_hostsim.py::test_sky_f32_equals_literal.
+constexpr float kSkyHalf[3] = {0.25f, 0.5f * 0.7f, 0.5f}; // k/2 for k = 0.5f, 0.7f, 1f
+
+RF_HD float sky_white(float ud1) { return __builtin_fmaf(-0.5f, ud1, 0.5f); }
+RF_HD float sky_blue(float ud1, float k_half) { return __builtin_fmaf(k_half, ud1, k_half); }
 
 RF_HD Colour sample_general(Rng &g, const CamDyn &cd, const CamStatic &cs, const Rect &rc,
                             float s, float t, const CheckerTable &tab)
@@ -373,12 +398,12 @@ RF_HD Colour sample_general(Rng &g, const CamDyn &cd, const CamStatic &cs, const
         ag = red ? 0.0f : 1.0f;
         ab = 0.0f;
     }
-    double T = sky_t(dx, dy, dz);
+    double T = sky_t(unit_dir_y(dx, dy, dz));
     float white = (float)(1.0 - T);
     Colour c;
-    c.r = sky_channel(T, white, 0.5f) * ar;
-    c.g = sky_channel(T, white, 0.7f) * ag;
-    c.b = sky_channel(T, white, 1.0f) * ab;
+    c.r = sky_channel_literal(T, white, 0.5f) * ar;
+    c.g = sky_channel_literal(T, white, 0.7f) * ag;
+    c.b = sky_channel_literal(T, white, 1.0f) * ab;
     return c;
 }
 
@@ -420,7 +445,21 @@ struct PixelEnv {
     float tt;   // rectangle.py:128
     bool tmiss; // rectangle.py:130
     float den;  // rectangle.py:168  x_max - x_min = half - (-half)
+    float rden; // RN(1 / den), for div_by_const
+    bool fast_div; // den in [2^-40, 2^40]: no intermediate of div_by_const can underflow
 };
+
+// Correctly rounded a / d for a divisor known in advance (Markstein): with r = RN(1/d),
+// q0 = RN(a*r) is within 1 ulp of a/d, the residual a - q0*d is exact in one fma, and
+// q = RN(q0 + rem*r) is RN(a/d) (no overflow/underflow in this path: a = p + half lies in
+// {0} U [2^-24*half, 2*half]).  3 VALU ops instead of the ~12 of an IEEE division.
+// Checked against '/' on 10^9 operand pairs by tests/test_hostsim.py.
+RF_HD float div_by_const(float a, float d, float rd)
+{
+    const float q0 = a * rd;
+    const float rem = __builtin_fmaf(-q0, d, a);
+    return __builtin_fmaf(rem, rd, q0);
+}
 
 RF_HD PixelEnv make_pixel_env(const float *cd, const float *rc)
 {
@@ -430,6 +469,8 @@ RF_HD PixelEnv make_pixel_env(const float *cd, const float *rc)
     e.tt = e.rect.z / e.dyn.llz;
     e.tmiss = (e.tt < 0.001f || e.tt > 1000000.0f);
     e.den = e.rect.half - (-e.rect.half);
+    e.rden = 1.0f / e.den;
+    e.fast_div = e.den >= 9.094947017729282e-13f && e.den <= 1099511627776.0f;
     return e;
 }
 
@@ -446,31 +487,40 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s,
     float px = ox + dx * e.tt;
     float py = oy + dy * e.tt;
     const float half = e.rect.half;
-    bool hit = !e.tmiss && !(px < -half || px > half || py < -half || py > half);
+    // rectangle.py:135: miss if p.x < -half or p.x > half or p.y < -half or p.y > half.
+    // == !(max(|p.x|, |p.y|) > half) including the NaN cases (maxNum drops a NaN operand,
+    // exactly as the four comparisons ignore it).
+    bool hit = !e.tmiss && !(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)) > half);
     bool red = false;
     if (hit) {
-        float u = (px + half) / e.den;
-        float v = (py + half) / e.den;
+        float u, v;
+        if (e.fast_div) { // per-environment condition: uniform across the block
+            u = div_by_const(px + half, e.den, e.rden);
+            v = div_by_const(py + half, e.den, e.rden);
+        } else {
+            u = (px + half) / e.den;
+            v = (py + half) / e.den;
+        }
         float q0, q1, q2;
         sphere_sample(g, q0, q1, q2);
         dx = q0;
         dy = q1;
         dz = 1.0f + q2;
-        red = (checker_sign(u, tab) * checker_sign(v, tab)) > 0;
+        red = checker_red(u, v, tab);
     }
-    double T = sky_t(dx, dy, dz);
-    float white = (float)(1.0 - T);
+    const float ud1 = unit_dir_y(dx, dy, dz);
+    const float white = sky_white(ud1);
     Colour c;
     if (hit) {
         // attenuation (1,0,0) or (0,1,0): the other channels contribute +0
-        float ch = sky_channel(T, white, red ? 0.5f : 0.7f);
+        float ch = add2(white, sky_blue(ud1, red ? kSkyHalf[0] : kSkyHalf[1]));
         c.r = red ? ch : 0.0f;
         c.g = red ? 0.0f : ch;
         c.b = 0.0f;
     } else {
-        c.r = sky_channel(T, white, 0.5f);
-        c.g = sky_channel(T, white, 0.7f);
-        c.b = sky_channel(T, white, 1.0f);
+        c.r = add2(white, sky_blue(ud1, kSkyHalf[0]));
+        c.g = add2(white, sky_blue(ud1, kSkyHalf[1]));
+        c.b = add2(white, sky_blue(ud1, kSkyHalf[2]));
     }
     return c;
 }
@@ -483,9 +533,18 @@ RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w
     cr = cg = cb = 0.0f;
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
-        float xi = rng_uniform48(g);
+        uint32_t xh, xl, yh, yl;
+        rng_next(g, xh, xl);
+        rng_next(g, yh, yl);
+        float xi, yi; // 2^48 * uniform
+        if (__builtin_expect((xh < yh ? xh : yh) < kFastHiMin, 0)) {
+            xi = unit_f32_scaled48_slow(xh, xl);
+            yi = unit_f32_scaled48_slow(yh, yl);
+        } else {
+            xi = unit_f32_scaled48_fast(xh, xl);
+            yi = unit_f32_scaled48_fast(yh, yl);
+        }
         float s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_literal(x, xi * kTwoM48, w);
-        float yi = rng_uniform48(g);
         float t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_literal(y, yi * kTwoM48, h);
         Colour c = AXIS ? sample_axis(g, e, cs.lens_radius, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);

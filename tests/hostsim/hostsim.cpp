@@ -93,7 +93,7 @@ long hs_check_checker(const float *us, const float *vs, long n)
         const double s1 = ((double)32.0f * 3.14159265358979323846) * (double)vs[i];
         const bool lit = sin(s0) * sin(s1) > 0.0;
         const bool fast = (checker_sign(us[i], tab) * checker_sign(vs[i], tab)) > 0;
-        if (lit != fast)
+        if (lit != fast || lit != checker_red(us[i], vs[i], tab))
             ++bad;
     }
     return bad;
@@ -139,6 +139,60 @@ long hs_check_accept(const uint64_t *words, long n, int dims, long *in_band)
             ++bad;
     }
     *in_band = band;
+    return bad;
+}
+
+// div_by_const against IEEE division: for each divisor d, numerators a = frac * d for
+// n_frac fractions in [0, 1] plus the exact multiples k/32 and their neighbours.
+long hs_check_div(const float *dens, long n_den, const float *fracs, long n_frac)
+{
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long i = 0; i < n_den; ++i) {
+        const float d = dens[i], rd = 1.0f / d;
+        for (long j = 0; j < n_frac; ++j) {
+            const float a = fracs[j] * d;
+            if ((a == 0.0f || a >= d * 2.98023223876953125e-08f) && !(div_by_const(a, d, rd) == a / d))
+                ++bad;
+        }
+        for (int k = 0; k <= 32; ++k) {
+            float a = d * ((float)k / 32.0f);
+            for (int s = -3; s <= 3; ++s) {
+                float b = a;
+                for (int t = 0; t < (s < 0 ? -s : s); ++t)
+                    b = __builtin_nextafterf(b, s < 0 ? -1.0f : 1e30f);
+                // the kernel's numerator is p + half with |p| <= half: 0 or >= 2^-25 * d
+                if ((b == 0.0f || b >= d * 2.98023223876953125e-08f) && !(div_by_const(b, d, rd) == b / d))
+                    ++bad;
+            }
+        }
+    }
+    return bad;
+}
+
+// f32 sky formulas against the literal f64 chain for every float in [lo_bits, hi_bits]
+// (two ranges: the non-negative and the negative floats up to 1 + 8 ulp).
+long hs_check_sky(void)
+{
+    long bad = 0;
+    const uint32_t top = 0x3F800008u; // 1 + 8 ulp
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long i = 0; i <= 2 * (long)top + 1; ++i) {
+        uint32_t bits = (i <= (long)top) ? (uint32_t)i : (0x80000000u | (uint32_t)(i - top - 1));
+        float ud;
+        __builtin_memcpy(&ud, &bits, 4);
+        const double T = sky_t(ud);
+        const float white_ref = (float)(1.0 - T);
+        if (!(white_ref == sky_white(ud)))
+            ++bad;
+        const float ks[3] = {0.5f, 0.7f, 1.0f};
+        for (int k = 0; k < 3; ++k) {
+            const float ref = sky_channel_literal(T, white_ref, ks[k]);
+            const float got = add2(sky_white(ud), sky_blue(ud, kSkyHalf[k]));
+            if (!(ref == got))
+                ++bad;
+        }
+    }
     return bad;
 }
 

@@ -32,6 +32,9 @@ def hs():
     lib.hs_check_checker.argtypes = [p, p, ctypes.c_long]
     lib.hs_render.argtypes = [p] + [ctypes.c_int] * 4 + [p] * 5 + [ctypes.c_double, p, ctypes.c_int]
     lib.hs_state_at.argtypes = [ctypes.c_uint64, ctypes.c_uint64, p]
+    lib.hs_check_div.restype = ctypes.c_long
+    lib.hs_check_div.argtypes = [p, ctypes.c_long, p, ctypes.c_long]
+    lib.hs_check_sky.restype = ctypes.c_long
     lib.hs_check_accept.restype = ctypes.c_long
     lib.hs_check_accept.argtypes = [p, ctypes.c_long, ctypes.c_int, p]
     return lib
@@ -101,6 +104,27 @@ def test_checker_sign_equals_libm_sin(hs):
     a, b = np.meshgrid(special, special)
     a, b = np.ascontiguousarray(a.ravel()), np.ascontiguousarray(b.ravel())
     assert hs.hs_check_checker(a.ctypes.data, b.ctypes.data, len(a)) == 0
+
+
+def test_div_by_const_equals_ieee_division(hs):
+    """uv = (p + half) / (half + half) through the 3-op Markstein form: 20000 divisors
+    (rectangle sides for targets in [0.001, 1e6], r_size 20 and 30, plus random floats)
+    x 50000 numerators each = 1e9 quotients, plus the k/32 checker boundaries."""
+    import math
+
+    rng = np.random.default_rng(21)
+    targets = np.concatenate([rng.uniform(5, 10, 8000), 10 ** rng.uniform(-3, 6, 8000)]).astype(np.float32)
+    halves = [(targets.astype(np.float64) * math.tan(math.radians(r / 2))).astype(np.float32) for r in (20, 30)]
+    dens = np.concatenate([h + h for h in halves] + [rng.uniform(0.01, 100, 4000).astype(np.float32)])[:20000]
+    fracs = np.concatenate([rng.random(49000, dtype=np.float32), np.linspace(0, 1, 1000, dtype=np.float32)])
+    dens, fracs = np.ascontiguousarray(dens), np.ascontiguousarray(fracs)
+    assert hs.hs_check_div(dens.ctypes.data, len(dens), fracs.ctypes.data, len(fracs)) == 0
+
+
+def test_sky_f32_equals_literal(hs):
+    """Every float32 ud.y in [-1 - 8 ulp, 1 + 8 ulp] (2.1e9 values): the four f32 fma forms
+    of the sky colour equal the reference's float64 chain."""
+    assert hs.hs_check_sky() == 0
 
 
 def _words_for(points):
