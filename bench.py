@@ -85,6 +85,22 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+def pmc_bytes_per_pixel():
+    """HBM bytes per rendered pixel of the render kernel from the committed rocprofv3 PMC
+    passes (profiles/<tag>_pmc.json: FETCH_SIZE doubled for gfx950's wide-read under-count,
+    WRITE_SIZE as is, divided by SQ_WAVES * 64 pixels).  None if no profile is present."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, e in data.items():
+        if "render_kernel" in name and e.get("SQ_WAVES") and "hbm_read_bytes_corrected" in e:
+            return (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / (e["SQ_WAVES"] * 64.0), os.path.basename(files[-1])
+    return None, None
+
+
 def shard_plan(rank, envs_per_gpu, frame):
     """Rank r owns global envs [r*E, (r+1)*E) and therefore the RNG states a single-device
     run of all envs would use for them (pixel index = e*h*w + y*w + x, render.py:217)."""
@@ -93,36 +109,35 @@ def shard_plan(rank, envs_per_gpu, frame):
 
 def cpu_baseline(frame, spp, n_envs):
     """The CPU oracle (a port: the reference's numba-CUDASIM path is not runnable here)
-    timed on this host's cores on a bounded sample of the same workload."""
+    timed on this host's cores on a bounded sample of the same workload (~12 s of work).
+    Seeding is untimed; to keep it short the sample's RNG states are the first env's
+    numba-seeded states tiled over the sampled envs (same arithmetic per pixel)."""
     from oracle import oracle as orc
     from reinfocus_amd.graphics import camera, world
 
     cores = min(os.cpu_count() or 1, 16)
     rng = np.random.Generator(np.random.PCG64DXSM(0))
-    if n_envs <= 0:
-        # calibrate on one env, then size the sample to ~15 s
-        n_envs = 1
-        calib = True
-    else:
-        calib = False
-    while True:
-        targets = rng.uniform(5, 10, n_envs).astype(np.float32)
-        focus = rng.uniform(5, 10, n_envs).astype(np.float32)
+    one_env = orc.seed_states(frame * frame, 0)
+
+    def run(n):
+        targets = rng.uniform(5, 10, n).astype(np.float32)
+        focus = rng.uniform(5, 10, n).astype(np.float32)
         cams = camera.FastCameras()
         cams.update(focus)
         worlds = world.FastWorlds()
         worlds.update(targets)
         dyn, origin, u, v, lens = cams.device_data()
-        states = orc.seed_states(n_envs * frame * frame, 0)
+        states = np.ascontiguousarray(np.tile(one_env, (n, 1)))
         t0 = time.perf_counter()
         frames = orc.render(dyn, worlds.device_data(), frame, frame, spp, states,
                             cs=orc.cam_static(origin, u, v, float(lens)), n_threads=cores)
         orc.focus_values(frames, 15, cores)
-        dt = time.perf_counter() - t0
-        if not calib:
-            break
-        n_envs = int(max(cores, min(512, round(15.0 / max(dt, 1e-3)))))
-        calib = False
+        return time.perf_counter() - t0
+
+    if n_envs <= 0:
+        dt = run(cores)  # calibration: one env per thread
+        n_envs = int(max(cores, min(4096, round(12.0 * cores / max(dt, 1e-3)))))
+    dt = run(n_envs)
     return {"value": n_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_envs} envs x {frame}x{frame} x {spp} spp, one render+focus pass of the C oracle "
                       f"(OpenMP, {cores} threads), {dt:.1f} s"}
@@ -212,6 +227,8 @@ def main(argv=None):
             render_s = timing["render_ms"] / 1000.0
             focus_s = timing["focus_ms"] / 1000.0
             achieved = RENDER_BYTES_PER_PIXEL * pixels / render_s / 1e9
+            launches = max(timing["render_launches"], 1)
+            pmc_bpp, pmc_file = pmc_bytes_per_pixel()
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": "render_kernel<AXIS,POW2>",
@@ -219,7 +236,10 @@ def main(argv=None):
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": None if pmc_bpp is None else pmc_bpp * pixels / launches,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": pmc_file,
+                "algorithmic_bytes_per_launch": RENDER_BYTES_PER_PIXEL * pixels / launches,
                 "algorithmic_bytes_per_pixel": RENDER_BYTES_PER_PIXEL,
                 "avg_launch_ms": timing["render_ms"] / max(timing["render_launches"], 1),
                 "launches": timing["render_launches"],
