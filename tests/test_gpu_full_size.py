@@ -1,0 +1,148 @@
+"""Parity at BASELINE.json's full sizes.  The oracle cannot render 4096 x 256^2 x 16 spp in
+seconds, so the full-size runs are checked through size-independent properties of the
+domain -- environments are independent given their RNG states -- plus bit-exact spot checks
+of randomly chosen environments against the oracle:
+
+ * spot check: any environment of the full render == the oracle's render of that environment
+   alone, started from the same 65536 RNG states (and the states end identical);
+ * shard invariance: rendering envs [a, b) on a context seeded at first_state_index = a*h*w
+   reproduces the corresponding slice of the single-context render (the multi-GPU contract);
+ * determinism: same seed, same scene -> same checksum; focus is invariant under image flips
+   (gray is pointwise, median / Laplacian kernels are symmetric, var is permutation invariant).
+"""
+
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from reinfocus_amd import _native
+
+    assert _native.device_count() >= 1
+    return _native
+
+
+def _scene(n, seed):
+    rng = np.random.Generator(np.random.PCG64DXSM(seed))
+    return helpers.pack_scene(*helpers.random_scene(rng, n))
+
+
+def _spot_check(oracle, ctx, scene, n, h, spp, picks, states_before, frames_getter):
+    dyn, rect, origin, u, v, lens = scene
+    cs = oracle.cam_static(origin, u, v, lens)
+    for e in picks:
+        st = states_before[e].copy()
+        want = oracle.render(dyn[e:e + 1], rect[e:e + 1], h, h, spp, st, cs=cs, n_threads=16)
+        got = frames_getter(e)
+        assert np.array_equal(got, want[0]), f"env {e} differs from the oracle"
+        assert np.array_equal(ctx.get_states(e * h * h, h * h), st), f"env {e} states differ"
+
+
+def test_headline_config_spot_checks_and_focus(native, oracle):
+    """BASELINE configs[2]: 4096 envs x 256 x 256 x 16 spp on one GPU."""
+    n, h, spp = 4096, 256, 16
+    scene = _scene(n, 42)
+    ctx = native.Context(0)
+    ctx.seed(n * h * h, 0, 0)
+    picks = [0, 1, 777, 2048, 4095]
+    before = {e: ctx.get_states(e * h * h, h * h) for e in picks}
+    ctx.set_scene(*scene)
+    fv = ctx.step(n, h, h, spp)
+    assert fv.shape == (n,) and np.all(np.isfinite(fv)) and np.all(fv >= 0)
+
+    def frame(e):
+        out = np.empty((1, h, h, 3), dtype=np.uint8)
+        native._check(native.load().rf_get_frames(ctx._h, e, 1, out.ctypes.data_as(native.ctypes.c_void_p)))
+        return out[0]
+
+    _spot_check(oracle, ctx, scene, n, h, spp, picks, before, frame)
+    want_fv = oracle.focus_values(np.stack([frame(e) for e in picks]))
+    assert np.max(np.abs(fv[picks] - want_fv)) < 1e-4           # BASELINE tolerance
+    assert np.allclose(fv[picks], want_fv, rtol=1e-12, atol=0)   # achieved
+
+    # in-focus environments score higher than strongly defocused ones (sanity at scale)
+    gap = np.abs(scene[1][:, 1] - scene[0][:, 0, 2])  # |(-target) - (-focus)|
+    assert fv[gap < 0.25].mean() > 2 * fv[gap > 3.0].mean()
+    ctx.close()
+
+
+def test_shard_invariance_and_determinism(native):
+    """Two 'GPUs' of 1024 envs each == one context of 2048 envs (BASELINE configs[3] logic)."""
+    n, h, spp = 2048, 128, 4
+    scene = _scene(n, 7)
+    dyn, rect, origin, u, v, lens = scene
+    whole = native.Context(0)
+    whole.seed(n * h * h, 0, 0)
+    whole.set_scene(*scene)
+    frames = whole.render(n, h, h, spp, to_host=True)
+    fv = whole.focus(n, h, h)
+    checksum = zlib.crc32(frames.tobytes())
+
+    half = n // 2
+    for r in range(2):
+        shard = native.Context(0)
+        shard.seed(half * h * h, 0, r * half * h * h)
+        shard.set_scene(dyn[r * half:(r + 1) * half], rect[r * half:(r + 1) * half], origin, u, v, lens)
+        part = shard.render(half, h, h, spp, to_host=True)
+        assert np.array_equal(part, frames[r * half:(r + 1) * half])
+        assert np.array_equal(shard.focus(half, h, h), fv[r * half:(r + 1) * half])
+        assert np.array_equal(shard.get_states(), whole.get_states(r * half * h * h, half * h * h))
+        shard.close()
+
+    again = native.Context(0)
+    again.seed(n * h * h, 0, 0)
+    again.set_scene(*scene)
+    assert zlib.crc32(again.render(n, h, h, spp, to_host=True).tobytes()) == checksum
+    again.close()
+
+    # flips leave every focus value unchanged, exactly
+    whole.upload_frames(np.ascontiguousarray(frames[:256, ::-1]))
+    assert np.array_equal(whole.focus(256, h, h), fv[:256])
+    whole.upload_frames(np.ascontiguousarray(frames[:256, :, ::-1]))
+    assert np.array_equal(whole.focus(256, h, h), fv[:256])
+    whole.close()
+
+
+def test_high_fidelity_config_spot_check(native, oracle):
+    """BASELINE configs[4] per-GPU share: 128 envs x 512 x 512 x 64 spp (1024 envs over 8 GPUs)."""
+    n, h, spp = 128, 512, 64
+    scene = _scene(n, 99)
+    ctx = native.Context(0)
+    ctx.seed(n * h * h, 0, 0)
+    picks = [3, 127]
+    before = {e: ctx.get_states(e * h * h, h * h) for e in picks}
+    ctx.set_scene(*scene)
+    fv = ctx.step(n, h, h, spp)
+
+    def frame(e):
+        out = np.empty((1, h, h, 3), dtype=np.uint8)
+        native._check(native.load().rf_get_frames(ctx._h, e, 1, out.ctypes.data_as(native.ctypes.c_void_p)))
+        return out[0]
+
+    _spot_check(oracle, ctx, scene, n, h, spp, picks, before, frame)
+    want = oracle.focus_values(np.stack([frame(e) for e in picks]))
+    assert np.allclose(fv[picks], want, rtol=1e-12, atol=0)
+    ctx.close()
+
+
+def test_first_hip_config(native, oracle):
+    """BASELINE configs[1]: 256 envs x 128 x 128 x 4 spp, every environment against the oracle."""
+    n, h, spp = 256, 128, 4
+    scene = _scene(n, 1)
+    ctx = native.Context(0)
+    ctx.seed(n * h * h, 0, 0)
+    ctx.set_scene(*scene)
+    st = oracle.seed_states(n * h * h, 0)
+    want = oracle.render(scene[0], scene[1], h, h, spp, st, n_threads=16)
+    got = ctx.render(n, h, h, spp, to_host=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.get_states(), st)
+    assert np.allclose(ctx.focus(n, h, h), oracle.focus_values(want, n_threads=16), rtol=1e-12, atol=0)
+    ctx.close()
