@@ -296,3 +296,21 @@ def test_errors_are_loud(native, ctx):
     ctx.render(1, 8, 8, 1)
     with pytest.raises(AssertionError):
         ctx.focus(1, 16, 16)  # shape mismatch with the frame buffer
+
+
+def test_fast_sqrt_and_reciprocal_are_ieee_exact(native):
+    """Every float in [2^-101, 2^101): the kernel's v_sqrt_f32 + residual fix-up and
+    v_rcp_f32 + two fma steps equal the IEEE-correct sqrtf / division (tests/gpucheck)."""
+    import ctypes
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "gpucheck", "libgpucheck.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck")])
+    lib = ctypes.CDLL(so)
+    out = (ctypes.c_ulonglong * 3)()
+    assert lib.gc_check_sqrt_rcp(out) == 0
+    assert out[2] > 1_600_000_000          # values visited
+    assert out[0] == 0, f"{out[0]} sqrt mismatches"
+    assert out[1] == 0, f"{out[1]} reciprocal mismatches"
