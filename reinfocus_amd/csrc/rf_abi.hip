@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -70,6 +71,7 @@ struct rf_ctx {
     int scene_cap = 0;
     rf::CamStatic cs{};
     bool axis = false;
+    bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
 
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;
@@ -198,6 +200,8 @@ int rf_create(int device, rf_ctx **out)
     RF_REQUIRE(ctx != nullptr, "rf_create: out of host memory");
     ctx->device = device;
     ctx->tab = make_checker_table();
+    if (const char *v = getenv("REINFOCUS_RENDER_COOP"))
+        ctx->coop = v[0] != '0';
 
     std::vector<rf::Mat128> tables;
     if (!rf::h_build_jump_tables(rf::kSeedMats, tables)) {
@@ -391,7 +395,11 @@ int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
             b.rect = a.rect + (size_t)e0 * 2;
             b.n = ne;
             const dim3 grid(gx, ne), block(rf::kBlock);
-            if (ctx->axis && pow2)
+            if (ctx->axis && ctx->coop && pow2)
+                hipLaunchKernelGGL((rf::render_kernel_coop<true>), grid, block, 0, ctx->stream, b);
+            else if (ctx->axis && ctx->coop)
+                hipLaunchKernelGGL((rf::render_kernel_coop<false>), grid, block, 0, ctx->stream, b);
+            else if (ctx->axis && pow2)
                 hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
             else if (ctx->axis)
                 hipLaunchKernelGGL((rf::render_kernel<true, false>), grid, block, 0, ctx->stream, b);

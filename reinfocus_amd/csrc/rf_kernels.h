@@ -89,6 +89,182 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// render_kernel_coop<POW2>: same arithmetic, canonical camera only, with the sphere
+// rejection loop made block-cooperative.
+//
+// In a wave whose 64 pixels all hit the target the loop of physics.py:31-44 runs for
+// max-over-lanes = ~6.5 trips although a lane needs 1.9 on average: after two trips 23 %
+// of the lanes are still looking for a candidate and they hold the whole wave.  Here every
+// lane makes at most kCoopTrips attempts in its own wave; the stragglers of all four waves
+// then park their RNG state in LDS, are packed densely onto the first lanes of the block
+// (one wave is usually enough for the ~58 of them), finish their loops there, and hand the
+// accepted draws and the advanced state back.  Which lane executes an attempt does not
+// matter -- the stream of a pixel is advanced by exactly the same draws -- so results are
+// bit-identical to render_kernel (and to the oracle).
+//
+// All 256 threads of a block run the sample loop in lockstep (dead threads of a partial
+// block included) so that every barrier is reached by every thread.
+// ---------------------------------------------------------------------------
+
+// Block-cooperative tail of a rejection loop.  `need` marks the lanes whose loop has not
+// accepted yet after their in-wave attempts; on return every such lane holds the advanced
+// RNG state and the accepted raw draws in w[0 .. 2*DIM).  DIM = 2: disc, DIM = 3: sphere.
+// `parity` selects the s_cnt buffer (callers alternate it between consecutive calls).
+struct CoopLds {
+    uint4 state[kBlock];
+    uint4 words4[kBlock];
+    uint2 words2[kBlock];
+    int cnt[2][kBlock / 64];
+};
+
+template <int DIM>
+__device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need, Rng &g, uint32_t *w)
+{
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const unsigned long long ballot = __ballot(need);
+    if ((tid & 63) == 0)
+        lds.cnt[parity][wave] = __popcll(ballot);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) {
+        const int c = lds.cnt[parity][i];
+        base += (i < wave) ? c : 0;
+        total += c;
+    }
+    if (total == 0) // block-uniform
+        return;
+    const int lane_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+    const int slot = base + lane_rank;
+    if (need)
+        lds.state[slot] = make_uint4(g.a_lo, g.a_hi, g.b_lo, g.b_hi);
+    __syncthreads();
+    if (tid < total) { // packed stragglers: finish their loops on the first lanes of the block
+        const uint4 ps = lds.state[tid];
+        Rng wg{ps.x, ps.y, ps.z, ps.w};
+        uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+        if (DIM == 2) {
+            while (!disc_attempt(wg, ww)) {
+            }
+        } else {
+            while (!sphere_attempt(wg, ww)) {
+            }
+        }
+        lds.state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+        lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        if (DIM == 3)
+            lds.words2[tid] = make_uint2(ww[4], ww[5]);
+    }
+    __syncthreads();
+    if (need) {
+        const uint4 ps = lds.state[slot];
+        g = Rng{ps.x, ps.y, ps.z, ps.w};
+        const uint4 w4 = lds.words4[slot];
+        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+        if (DIM == 3) {
+            const uint2 w2 = lds.words2[slot];
+            w[4] = w2.x; w[5] = w2.y;
+        }
+    }
+}
+
+#ifndef RF_COOP_TRIPS
+#define RF_COOP_TRIPS 2
+#endif
+#ifndef RF_COOP_DISC
+#define RF_COOP_DISC 1 // in-wave disc attempts before the cooperative tail; 0 = disc loop stays in-wave
+#endif
+constexpr int kCoopTrips = RF_COOP_TRIPS;
+
+template <bool POW2>
+__global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
+{
+    __shared__ uint32_t stage[kBlock * 3 / 4];
+    __shared__ CoopLds lds;
+
+    const int e = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x * kBlock + tid; // pixel within the env
+    const bool live = p < a.hw;
+    const int y = live ? p / a.w : 0;
+    const int x = live ? p - y * a.w : 0;
+    const size_t pix = (size_t)e * a.hw + (live ? p : 0);
+
+    Rng g = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull); // dead lanes: any state
+    if (live) {
+        const ulonglong2 st = a.states[pix];
+        g = rng_load(st.x, st.y);
+    }
+    const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
+    const float xf = (float)x, yf = (float)y;
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    for (int k = 0; k < a.spp; ++k) {
+        float s, t;
+        sample_coords<POW2>(g, x, y, xf, yf, a.h, a.w, a.inv_w, a.inv_h, s, t);
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+#if RF_COOP_DISC
+        bool dneed = live;
+        for (int trip = 0; trip < RF_COOP_DISC; ++trip) {
+            if (__any(dneed)) {
+                if (dneed && disc_attempt(g, w))
+                    dneed = false;
+            }
+        }
+        coop_finish<2>(lds, 0, dneed, g, w);
+        float p0, p1;
+        disc_finish(w, p0, p1);
+        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s, t, a.tab);
+#else
+        const AxisPre pre = sample_axis_pre(g, env, a.cs.lens_radius, s, t, a.tab);
+#endif
+
+        bool need = live && pre.hit;
+        for (int trip = 0; trip < kCoopTrips; ++trip) {
+            if (__any(need)) { // wave-uniform
+                if (need && sphere_attempt(g, w))
+                    need = false;
+            }
+        }
+        coop_finish<3>(lds, 1, need, g, w);
+
+        float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+        if (pre.hit)
+            sphere_finish(w, q0, q1, q2);
+        const Colour c = sample_axis_shade(pre, q0, q1, q2);
+        cr = add2(cr, c.r);
+        cg = add2(cg, c.g);
+        cb = add2(cb, c.b);
+    }
+    if (live)
+        a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
+
+    const uint8_t r8 = (uint8_t)(cr * a.scale);
+    const uint8_t g8 = (uint8_t)(cg * a.scale);
+    const uint8_t b8 = (uint8_t)(cb * a.scale);
+    const size_t block_px = (size_t)e * a.hw + (size_t)blockIdx.x * kBlock;
+    if ((a.hw & 3) == 0) {
+        uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+        sb[tid * 3 + 0] = r8;
+        sb[tid * 3 + 1] = g8;
+        sb[tid * 3 + 2] = b8;
+        __syncthreads();
+        const int count = min(kBlock, a.hw - (int)blockIdx.x * kBlock);
+        const int ndw = count * 3 / 4;
+        if (tid < ndw) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(a.frames + block_px * 3);
+            dst[tid] = stage[tid];
+        }
+    } else if (live) {
+        uint8_t *dst = a.frames + (block_px + tid) * 3;
+        dst[0] = r8;
+        dst[1] = g8;
+        dst[2] = b8;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // focus: gray -> median3x3 (replicate) -> Laplacian (reflect-101, sat u8) -> sums
 // One block per (row band, env).  Integer/byte work, HBM-bound: 3 B/pixel read.
 // ---------------------------------------------------------------------------

@@ -242,47 +242,66 @@ RF_HD float exact_pm1(uint32_t r_hi, uint32_t r_lo)
     return __builtin_fmaf(unit_f32_scaled48(r_hi, r_lo), kTwoM47, -1.0f);
 }
 
+// One attempt of camera.py:229-252 random_in_unit_disc: two draws (raw words kept in
+// w = {ah, al, bh, bl}); true when the reference accepts, i.e. p0*p0 + p1*p1 < 1 in f32.
+RF_HD bool disc_attempt(Rng &g, uint32_t w[4])
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]);
+    const float sq = __builtin_fmaf(ta, ta, tb * tb);
+    bool accept = sq < 1.0f - kAcceptBand;
+    if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0)) {
+        const float e0 = exact_pm1(w[0], w[1]), e1 = exact_pm1(w[2], w[3]);
+        const float d0 = e0 * e0, d1 = e1 * e1;
+        accept = d0 + d1 < 1.0f;
+    }
+    return accept;
+}
+
+RF_HD void disc_finish(const uint32_t w[4], float &p0, float &p1)
+{
+    p0 = exact_pm1(w[0], w[1]);
+    p1 = exact_pm1(w[2], w[3]);
+}
+
 RF_HD void disc_sample(Rng &g, float &p0, float &p1)
 {
-    // camera.py:229-252: accept when p0*p0 + p1*p1 < 1 (f32 products, f32 sum)
-    uint32_t ah, al, bh, bl;
-    for (;;) {
-        rng_next(g, ah, al);
-        rng_next(g, bh, bl);
-        const float ta = approx_pm1(ah), tb = approx_pm1(bh);
-        const float sq = __builtin_fmaf(ta, ta, tb * tb);
-        bool accept = sq < 1.0f - kAcceptBand;
-        if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0)) {
-            const float e0 = exact_pm1(ah, al), e1 = exact_pm1(bh, bl);
-            const float d0 = e0 * e0, d1 = e1 * e1;
-            accept = d0 + d1 < 1.0f;
-        }
-        if (accept)
-            break;
+    uint32_t w[4];
+    while (!disc_attempt(g, w)) {
     }
-    p0 = exact_pm1(ah, al);
-    p1 = exact_pm1(bh, bl);
+    disc_finish(w, p0, p1);
+}
+
+// One attempt of physics.py:20-44 random_in_unit_sphere: three draws (raw words kept in
+// w = {ah, al, bh, bl, ch, cl}); true when the reference accepts the candidate, i.e. when
+// float32(q0**2) + float32(q1**2) + float32(q2**2) < 1.
+RF_HD bool sphere_attempt(Rng &g, uint32_t w[6])
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    rng_next(g, w[4], w[5]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]), tc = approx_pm1(w[4]);
+    const float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
+    bool accept = sq < 1.0f - kAcceptBand;
+    if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0))
+        accept = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5])) < 1.0f;
+    return accept;
+}
+
+RF_HD void sphere_finish(const uint32_t w[6], float &q0, float &q1, float &q2)
+{
+    q0 = exact_pm1(w[0], w[1]);
+    q1 = exact_pm1(w[2], w[3]);
+    q2 = exact_pm1(w[4], w[5]);
 }
 
 RF_HD void sphere_sample(Rng &g, float &q0, float &q1, float &q2)
 {
-    // physics.py:20-44: accept when float32(q0**2) + float32(q1**2) + float32(q2**2) < 1
-    uint32_t ah, al, bh, bl, ch, cl;
-    for (;;) {
-        rng_next(g, ah, al);
-        rng_next(g, bh, bl);
-        rng_next(g, ch, cl);
-        const float ta = approx_pm1(ah), tb = approx_pm1(bh), tc = approx_pm1(ch);
-        const float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
-        bool accept = sq < 1.0f - kAcceptBand;
-        if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0))
-            accept = sq_len(exact_pm1(ah, al), exact_pm1(bh, bl), exact_pm1(ch, cl)) < 1.0f;
-        if (accept)
-            break;
+    uint32_t w[6];
+    while (!sphere_attempt(g, w)) {
     }
-    q0 = exact_pm1(ah, al);
-    q1 = exact_pm1(bh, bl);
-    q2 = exact_pm1(ch, cl);
+    sphere_finish(w, q0, q1, q2);
 }
 
 // physics.py:183-193: sky colour of direction d times attenuation.
@@ -483,25 +502,31 @@ RF_HD PixelEnv make_pixel_env(const float *cd, const float *rc)
     return e;
 }
 
-RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s, float t,
-                         const CheckerTable &tab)
+// camera.get_ray + rectangle.fast_hit (+ uv / checker colour on a hit) of one sample for
+// the canonical camera frame: everything before the scatter's random_in_unit_sphere.
+struct AxisPre {
+    bool hit, red;
+    float dx, dy, dz; // primary ray direction (the sky direction of a miss)
+};
+
+RF_HD AxisPre sample_axis_ray(float p0, float p1, const PixelEnv &e, double lens_radius, float s, float t,
+                              const CheckerTable &tab)
 {
-    float p0, p1;
-    disc_sample(g, p0, p1);
     float ox = (float)((double)p0 * lens_radius);
     float oy = (float)((double)p1 * lens_radius);
-    float dx = (e.dyn.llx + e.dyn.hx * s) - ox;
-    float dy = (e.dyn.lly + e.dyn.vy * t) - oy;
-    float dz = e.dyn.llz;
-    float px = ox + dx * e.tt;
-    float py = oy + dy * e.tt;
+    AxisPre r;
+    r.dx = (e.dyn.llx + e.dyn.hx * s) - ox;
+    r.dy = (e.dyn.lly + e.dyn.vy * t) - oy;
+    r.dz = e.dyn.llz;
+    float px = ox + r.dx * e.tt;
+    float py = oy + r.dy * e.tt;
     const float half = e.rect.half;
     // rectangle.py:135: miss if p.x < -half or p.x > half or p.y < -half or p.y > half.
     // == !(max(|p.x|, |p.y|) > half) including the NaN cases (maxNum drops a NaN operand,
     // exactly as the four comparisons ignore it).
-    bool hit = !e.tmiss && !(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)) > half);
-    bool red = false;
-    if (hit) {
+    r.hit = !e.tmiss && !(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)) > half);
+    r.red = false;
+    if (r.hit) {
         float u, v;
         if (e.fast_div) { // per-environment condition: uniform across the block
             u = div_by_const(px + half, e.den, e.rden);
@@ -510,21 +535,24 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s,
             u = (px + half) / e.den;
             v = (py + half) / e.den;
         }
-        float q0, q1, q2;
-        sphere_sample(g, q0, q1, q2);
-        dx = q0;
-        dy = q1;
-        dz = 1.0f + q2;
-        red = checker_red(u, v, tab);
+        r.red = checker_red(u, v, tab);
     }
+    return r;
+}
+
+// physics.fast_find_colour's tail (physics.py:183-193) for a hit (scattered direction
+// N + q = (q0, q1, 1 + q2), attenuation red or green) or a miss (primary direction).
+RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
+{
+    const float dx = r.hit ? q0 : r.dx, dy = r.hit ? q1 : r.dy, dz = r.hit ? 1.0f + q2 : r.dz;
     const float ud1 = unit_dir_y(dx, dy, dz);
     const float white = sky_white(ud1);
     Colour c;
-    if (hit) {
+    if (r.hit) {
         // attenuation (1,0,0) or (0,1,0): the other channels contribute +0
-        float ch = add2(white, sky_blue(ud1, red ? kSkyHalf[0] : kSkyHalf[1]));
-        c.r = red ? ch : 0.0f;
-        c.g = red ? 0.0f : ch;
+        float ch = add2(white, sky_blue(ud1, r.red ? kSkyHalf[0] : kSkyHalf[1]));
+        c.r = r.red ? ch : 0.0f;
+        c.g = r.red ? 0.0f : ch;
         c.b = 0.0f;
     } else {
         c.r = add2(white, sky_blue(ud1, kSkyHalf[0]));
@@ -532,6 +560,37 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s,
         c.b = add2(white, sky_blue(ud1, kSkyHalf[2]));
     }
     return c;
+}
+
+RF_HD AxisPre sample_axis_pre(Rng &g, const PixelEnv &e, double lens_radius, float s, float t,
+                              const CheckerTable &tab)
+{
+    float p0, p1;
+    disc_sample(g, p0, p1);
+    return sample_axis_ray(p0, p1, e, lens_radius, s, t, tab);
+}
+
+RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s, float t,
+                         const CheckerTable &tab)
+{
+    const AxisPre r = sample_axis_pre(g, e, lens_radius, s, t, tab);
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+    if (r.hit)
+        sphere_sample(g, q0, q1, q2);
+    return sample_axis_shade(r, q0, q1, q2);
+}
+
+// jittered pixel coordinates of one sample (render.py:229-234), two draws
+template <bool POW2>
+RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, int h, int w, float inv_w, float inv_h,
+                         float &s, float &t)
+{
+    uint32_t xh, xl, yh, yl;
+    rng_next(g, xh, xl);
+    rng_next(g, yh, yl);
+    const float xi = unit_f32_scaled48(xh, xl), yi = unit_f32_scaled48(yh, yl); // 2^48 * uniform
+    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_literal(x, xi * kTwoM48, w);
+    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_literal(y, yi * kTwoM48, h);
 }
 
 template <bool AXIS, bool POW2>
@@ -542,12 +601,8 @@ RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w
     cr = cg = cb = 0.0f;
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
-        uint32_t xh, xl, yh, yl;
-        rng_next(g, xh, xl);
-        rng_next(g, yh, yl);
-        const float xi = unit_f32_scaled48(xh, xl), yi = unit_f32_scaled48(yh, yl); // 2^48 * uniform
-        float s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_literal(x, xi * kTwoM48, w);
-        float t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_literal(y, yi * kTwoM48, h);
+        float s, t;
+        sample_coords<POW2>(g, x, y, xf, yf, h, w, inv_w, inv_h, s, t);
         Colour c = AXIS ? sample_axis(g, e, cs.lens_radius, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);
         cr = add2(cr, c.r);
