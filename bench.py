@@ -231,7 +231,7 @@ def main(argv=None):
             pmc_bpp, pmc_file = pmc_bytes_per_pixel()
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "render_kernel<AXIS,POW2>",
+                "kernel": "render_kernel_coop<POW2>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

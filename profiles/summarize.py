@@ -16,13 +16,14 @@ import sys
 def main(tag):
     root = os.path.dirname(os.path.abspath(__file__))
     src = os.path.join(root, "..", "gpurun_out", "prof_" + tag)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    # gpurun merges successive calls into the same directory: keep the newest run of each pass
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     assert stats, "no kernel_stats.csv under " + src
-    shutil.copy(stats[0], os.path.join(root, tag + "_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(root, tag + "_kernel_stats.csv"))
     totals = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
     for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
-        for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+        for f in sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
             seen = set()
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"].split("(")[0]
