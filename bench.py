@@ -43,6 +43,9 @@ def parse_args(argv=None):
     ap.add_argument("--frame", type=int, default=256)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--cpu-baseline-envs", type=int, default=0, help="0 = choose ~15 s of CPU work")
+    ap.add_argument("--env", choices=["device", "host"], default="device",
+                    help="device: whole step resident on the GPU (rf_env_*); host: numpy glue around "
+                         "rf_render / rf_focus (identical results, tests/test_gpu_environment.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="no GPU work: exercises only the multi-rank plumbing (CPU tests)")
@@ -158,10 +161,10 @@ def main(argv=None):
         if _native.device_count() < 1:
             raise SystemExit("bench.py needs a GPU: reinfocus_amd has no CPU fallback")
         device = int(os.environ.get("REINFOCUS_BENCH_DEVICE", ranks.local_rank))
-        env = harness.VectorDiscreteSteps(num_envs=n_local, frame_height=frame, samples_per_pixel=spp,
-                                          seed=ranks.rank, device=device,
-                                          first_state_index=plan["first_state_index"])
-        ctx = env._renderer._ctx
+        env_cls = harness.DeviceVectorDiscreteSteps if args.env == "device" else harness.VectorDiscreteSteps
+        env = env_cls(num_envs=n_local, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank,
+                      device=device, first_state_index=plan["first_state_index"])
+        ctx = env._ctx if args.env == "device" else env._renderer._ctx
         env.reset()
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
@@ -219,6 +222,7 @@ def main(argv=None):
                 "spp": spp,
                 "auto_resets_per_step": total_resets / max(args.steps, 1),
                 "sharding": "independent env ranges per rank, no data-path collective",
+                "env_glue": "device-resident (rf_env_step)" if args.env == "device" else "host numpy (harness)",
             },
         }
         if timing is not None:

@@ -118,6 +118,55 @@ int rf_timing(rf_ctx *ctx, int enable);
 int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches,
                    double *focus_ms, uint64_t *focus_launches);
 
+/* ---- device-resident DiscreteSteps-v0 step ------------
+ * The per-step numpy glue of the reference's vector environment runs on the GPU around
+ * the render and focus kernels; a step uploads the actions and a pool of candidate reset
+ * states and downloads observations, rewards and flags.
+ * Replaces, for the environment assembled in examples/custom_environments.py:114-241:
+ *   VectorEnvironment.reset / step        environments/vector_environment.py:75-164
+ *   DiscreteMoveTransformer.transform     environments/state_transformer.py:248-266
+ *   TimeLimitEnder | DivergingEnder       environments/episode_ender.py:106-207, :580-656
+ *   Normalized(Delta([Indexed, Focus]))   environments/state_observer.py:232-292, :472-517
+ *   Delta + Observation + OnTarget reward environments/episode_rewarder.py:86-155, :210-292
+ *   FastCameras / FastWorlds packing      graphics/camera.py:144-179, graphics/world.py:110-123
+ */
+typedef struct rf_env_config {
+    int n;                    /* environments */
+    int n_actions;            /* <= 32 */
+    double action_set[32];    /* moves of the focus plane (float64, as the reference) */
+    float limit_lo, limit_hi; /* clip limits of the state */
+    int max_steps;            /* TimeLimitEnder; <= 0 disables it */
+    float diverge_threshold;  /* DivergingEnder threshold */
+    int early_end_steps;      /* DivergingEnder early_end_steps */
+    float mid[4], scale[4];   /* NormalizedObserver mid / scale (float32) */
+    float reward_scale;       /* DeltaRewarder scale */
+    float on_target_span;     /* OnTargetRewarder span */
+    double half_width, half_height; /* FastCameras: aspect * tan(vfov/2), tan(vfov/2) */
+    double tan_half_r;        /* FastWorlds: tan(radians(r_size / 2)) */
+    float look_from[3], cam_u[3], cam_v[3], cam_w[3];
+    double lens_radius;
+    int frame_height, spp, gray_mode;
+} rf_env_config;
+
+/* Allocates the per-env device state for cfg->n environments (RNG states must already
+ * cover n * frame_height^2 pixels: rf_seed first). */
+int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg);
+
+/* vector_environment.py:75-102: installs host_states float32[n][2] = [target, focus plane],
+ * renders and scores every environment, returns observations float32[n][4]. */
+int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs);
+
+/* vector_environment.py:104-164: one step.  host_actions int32[n]; host_pool float32[n][2]
+ * holds the initializer's candidate states, the r-th done environment (in index order)
+ * takes row r; *host_n_reset returns how many rows were consumed.  Outputs:
+ * observations float32[n][4], rewards float64[n], truncated uint8[n] (terminated is always
+ * false for this environment). */
+int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool, float *host_obs,
+                double *host_rewards, uint8_t *host_truncated, int *host_n_reset);
+
+/* Current states float32[n][2] (tests / checkpoint). */
+int rf_env_get_states(rf_ctx *ctx, float *host_states);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,7 +42,41 @@ SYMBOLS = (
     "rf_synchronize",
     "rf_timing",
     "rf_timing_read",
+    "rf_env_configure",
+    "rf_env_reset",
+    "rf_env_step",
+    "rf_env_get_states",
 )
+
+
+class EnvConfig(ctypes.Structure):
+    """rf_env_config (include/reinfocus_hip.h)."""
+
+    _fields_ = [
+        ("n", ctypes.c_int),
+        ("n_actions", ctypes.c_int),
+        ("action_set", ctypes.c_double * 32),
+        ("limit_lo", ctypes.c_float),
+        ("limit_hi", ctypes.c_float),
+        ("max_steps", ctypes.c_int),
+        ("diverge_threshold", ctypes.c_float),
+        ("early_end_steps", ctypes.c_int),
+        ("mid", ctypes.c_float * 4),
+        ("scale", ctypes.c_float * 4),
+        ("reward_scale", ctypes.c_float),
+        ("on_target_span", ctypes.c_float),
+        ("half_width", ctypes.c_double),
+        ("half_height", ctypes.c_double),
+        ("tan_half_r", ctypes.c_double),
+        ("look_from", ctypes.c_float * 3),
+        ("cam_u", ctypes.c_float * 3),
+        ("cam_v", ctypes.c_float * 3),
+        ("cam_w", ctypes.c_float * 3),
+        ("lens_radius", ctypes.c_double),
+        ("frame_height", ctypes.c_int),
+        ("spp", ctypes.c_int),
+        ("gray_mode", ctypes.c_int),
+    ]
 
 
 class NativeLibraryMissing(ImportError):
@@ -84,6 +118,10 @@ def load():
     lib.rf_timing.argtypes = [vp, i32]
     lib.rf_timing_read.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(u64), ctypes.POINTER(dbl),
                                    ctypes.POINTER(u64)]
+    lib.rf_env_configure.argtypes = [vp, ctypes.POINTER(EnvConfig)]
+    lib.rf_env_reset.argtypes = [vp, vp, vp]
+    lib.rf_env_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
+    lib.rf_env_get_states.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -194,6 +232,34 @@ class Context:
     def step(self, n, h, w, spp, gray_mode=GRAY_15BIT):
         out = np.empty(n, dtype=np.float64)
         _check(self._lib.rf_step(self._h, n, h, w, spp, gray_mode, _ptr(out)))
+        return out
+
+    # --- device-resident env step ----------------------------------------------------------
+    def env_configure(self, cfg):
+        self._env_n = cfg.n
+        _check(self._lib.rf_env_configure(self._h, ctypes.byref(cfg)))
+
+    def env_reset(self, states):
+        states = np.ascontiguousarray(states, dtype=np.float32).reshape(self._env_n, 2)
+        obs = np.empty((self._env_n, 4), dtype=np.float32)
+        _check(self._lib.rf_env_reset(self._h, _ptr(states), _ptr(obs)))
+        return obs
+
+    def env_step(self, actions, pool):
+        n = self._env_n
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(n)
+        pool = np.ascontiguousarray(pool, dtype=np.float32).reshape(n, 2)
+        obs = np.empty((n, 4), dtype=np.float32)
+        rewards = np.empty(n, dtype=np.float64)
+        truncated = np.empty(n, dtype=np.uint8)
+        k = ctypes.c_int(0)
+        _check(self._lib.rf_env_step(self._h, _ptr(actions), _ptr(pool), _ptr(obs), _ptr(rewards), _ptr(truncated),
+                                     ctypes.byref(k)))
+        return obs, rewards, truncated.astype(bool), k.value
+
+    def env_states(self):
+        out = np.empty((self._env_n, 2), dtype=np.float32)
+        _check(self._lib.rf_env_get_states(self._h, _ptr(out)))
         return out
 
     def synchronize(self):

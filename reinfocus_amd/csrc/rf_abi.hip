@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 
+#include "rf_env.h"
 #include "rf_jump.h"
 #include "rf_kernels.h"
 
@@ -82,6 +83,16 @@ struct rf_ctx {
     int focus_cap = 0;
 
     rf::CheckerTable tab{};
+
+    // device-resident env step (rf_env_*)
+    bool env_ready = false;
+    rf::EnvConfig env_cfg{};
+    rf::EnvState env{};
+    rf_env_config env_host{};
+    void *env_block = nullptr; // one allocation holding every EnvState array
+    int *d_actions = nullptr;
+    float *d_pool = nullptr;
+    bool env_axis = false;
 
     bool timing = false;
     std::vector<EventPair> ev_render, ev_focus;
@@ -246,6 +257,7 @@ int rf_destroy(rf_ctx *ctx)
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_var) (void)hipFree(ctx->d_var);
+    if (ctx->env_block) (void)hipFree(ctx->env_block);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RF_OK;
@@ -351,26 +363,19 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
     return RF_OK;
 }
 
-int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
+namespace {
+
+// enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
+int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, const float *rect, bool axis)
 {
-    RF_REQUIRE(ctx != nullptr, "rf_render: ctx is NULL");
-    RF_REQUIRE(ctx->scene_n > 0, "rf_render: no scene uploaded (rf_set_scene first)");
-    RF_REQUIRE(n == ctx->scene_n, "rf_render: n=%d but the scene holds %d environments", n, ctx->scene_n);
-    RF_REQUIRE(h > 0 && w > 0 && spp > 0, "rf_render: h, w, spp must be positive");
-    RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render: frame too large");
-    const uint64_t need = (uint64_t)n * h * w;
-    RF_REQUIRE(need <= ctx->n_states, "rf_render: %llu pixels but only %llu RNG states (rf_seed first)",
-               (unsigned long long)need, (unsigned long long)ctx->n_states);
-    RF_HIP(hipSetDevice(ctx->device));
     int rc = ensure_frames(ctx, n, h, w);
     if (rc != RF_OK)
         return rc;
-
     rf::RenderArgs a;
     a.frames = ctx->d_frames;
     a.states = ctx->d_states;
-    a.cam_dyn = ctx->d_cam;
-    a.rect = ctx->d_rect;
+    a.cam_dyn = cam;
+    a.rect = rect;
     a.cs = ctx->cs;
     a.tab = ctx->tab;
     a.n = n;
@@ -395,13 +400,13 @@ int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
             b.rect = a.rect + (size_t)e0 * 2;
             b.n = ne;
             const dim3 grid(gx, ne), block(rf::kBlock);
-            if (ctx->axis && ctx->coop && pow2)
+            if (axis && ctx->coop && pow2)
                 hipLaunchKernelGGL((rf::render_kernel_coop<true>), grid, block, 0, ctx->stream, b);
-            else if (ctx->axis && ctx->coop)
+            else if (axis && ctx->coop)
                 hipLaunchKernelGGL((rf::render_kernel_coop<false>), grid, block, 0, ctx->stream, b);
-            else if (ctx->axis && pow2)
+            else if (axis && pow2)
                 hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
-            else if (ctx->axis)
+            else if (axis)
                 hipLaunchKernelGGL((rf::render_kernel<true, false>), grid, block, 0, ctx->stream, b);
             else if (pow2)
                 hipLaunchKernelGGL((rf::render_kernel<false, true>), grid, block, 0, ctx->stream, b);
@@ -410,11 +415,27 @@ int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
         }
     }
     RF_HIP(hipGetLastError());
-    if (ctx->ev_render.size() > 512) {
-        rc = drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
-        if (rc != RF_OK)
-            return rc;
-    }
+    if (ctx->ev_render.size() > 512)
+        return drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
+    return RF_OK;
+}
+
+} // namespace
+
+int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_render: ctx is NULL");
+    RF_REQUIRE(ctx->scene_n > 0, "rf_render: no scene uploaded (rf_set_scene first)");
+    RF_REQUIRE(n == ctx->scene_n, "rf_render: n=%d but the scene holds %d environments", n, ctx->scene_n);
+    RF_REQUIRE(h > 0 && w > 0 && spp > 0, "rf_render: h, w, spp must be positive");
+    RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render: frame too large");
+    const uint64_t need = (uint64_t)n * h * w;
+    RF_REQUIRE(need <= ctx->n_states, "rf_render: %llu pixels but only %llu RNG states (rf_seed first)",
+               (unsigned long long)need, (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    int rc = launch_render(ctx, n, h, w, spp, ctx->d_cam, ctx->d_rect, ctx->axis);
+    if (rc != RF_OK)
+        return rc;
     if (host_out)
         return rf_get_frames(ctx, 0, n, host_out);
     return RF_OK;
@@ -448,16 +469,13 @@ int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in)
     return RF_OK;
 }
 
-int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var)
+namespace {
+
+// enqueues the focus measure of the first n frames into ctx->d_var (device)
+int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
 {
-    RF_REQUIRE(ctx != nullptr && host_var != nullptr, "rf_focus: NULL argument");
-    RF_REQUIRE(n > 0 && n <= ctx->fn && h == ctx->fh && w == ctx->fw,
-               "rf_focus: asked for %dx%dx%d but the frame buffer holds %dx%dx%d", n, h, w, ctx->fn, ctx->fh,
-               ctx->fw);
-    RF_REQUIRE(gray_mode == RF_GRAY_15BIT || gray_mode == RF_GRAY_14BIT, "rf_focus: gray_mode must be 14 or 15");
     const size_t lds = (((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15;
     RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);
-    RF_HIP(hipSetDevice(ctx->device));
     if (n > ctx->focus_cap) {
         RF_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->d_sums) RF_HIP(hipFree(ctx->d_sums));
@@ -488,6 +506,22 @@ int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var)
                            ctx->d_var, n, (unsigned long long)h * (unsigned long long)w);
     }
     RF_HIP(hipGetLastError());
+    return RF_OK;
+}
+
+} // namespace
+
+int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var)
+{
+    RF_REQUIRE(ctx != nullptr && host_var != nullptr, "rf_focus: NULL argument");
+    RF_REQUIRE(n > 0 && n <= ctx->fn && h == ctx->fh && w == ctx->fw,
+               "rf_focus: asked for %dx%dx%d but the frame buffer holds %dx%dx%d", n, h, w, ctx->fn, ctx->fh,
+               ctx->fw);
+    RF_REQUIRE(gray_mode == RF_GRAY_15BIT || gray_mode == RF_GRAY_14BIT, "rf_focus: gray_mode must be 14 or 15");
+    RF_HIP(hipSetDevice(ctx->device));
+    int rc = launch_focus(ctx, n, h, w, gray_mode);
+    if (rc != RF_OK)
+        return rc;
     RF_HIP(hipMemcpyAsync(host_var, ctx->d_var, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));
     return RF_OK;
@@ -539,6 +573,178 @@ int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches, do
     if (focus_ms) *focus_ms = ctx->focus_ms;
     if (focus_launches) *focus_launches = ctx->focus_n;
     return rc;
+}
+
+/* ---- device-resident env step ------------------------------------------------------------ */
+
+int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
+{
+    RF_REQUIRE(ctx != nullptr && cfg != nullptr, "rf_env_configure: NULL argument");
+    RF_REQUIRE(cfg->n > 0 && cfg->n_actions > 0 && cfg->n_actions <= 32, "rf_env_configure: bad n / n_actions");
+    RF_REQUIRE(cfg->frame_height > 0 && cfg->spp > 0, "rf_env_configure: frame_height, spp must be positive");
+    RF_REQUIRE(cfg->gray_mode == RF_GRAY_15BIT || cfg->gray_mode == RF_GRAY_14BIT, "rf_env_configure: gray_mode");
+    const uint64_t need = (uint64_t)cfg->n * cfg->frame_height * cfg->frame_height;
+    RF_REQUIRE(need <= ctx->n_states, "rf_env_configure: %llu pixels but only %llu RNG states (rf_seed first)",
+               (unsigned long long)need, (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->env_block) {
+        RF_HIP(hipFree(ctx->env_block));
+        ctx->env_block = nullptr;
+    }
+    ctx->env_ready = false;
+    const size_t n = (size_t)cfg->n;
+    // carve one allocation (256-B aligned pieces)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_state = take(n * 8), o_steps = take(n * 4), o_div = take(n * 4), o_last = take(n * 4),
+                 o_oldw = take(n * 8), o_oldf = take(n * 4), o_cam = take(n * 36), o_rect = take(n * 8),
+                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_cnt = take(4),
+                 o_obs = take(n * 16), o_rew = take(n * 8), o_trunc = take(n), o_done = take(n),
+                 o_act = take(n * 4), o_pool = take(n * 8);
+    RF_HIP(hipMalloc(&ctx->env_block, off));
+    RF_HIP(hipMemsetAsync(ctx->env_block, 0, off, ctx->stream));
+    char *base = (char *)ctx->env_block;
+    rf::EnvState &s = ctx->env;
+    s.state = (float *)(base + o_state);
+    s.steps = (int *)(base + o_steps);
+    s.diverging = (int *)(base + o_div);
+    s.last_diff = (float *)(base + o_last);
+    s.old_wrapped = (float *)(base + o_oldw);
+    s.old_focus = (float *)(base + o_oldf);
+    s.cam_dyn = (float *)(base + o_cam);
+    s.rect = (float *)(base + o_rect);
+    s.cam_dyn2 = (float *)(base + o_cam2);
+    s.rect2 = (float *)(base + o_rect2);
+    s.done_index = (int *)(base + o_didx);
+    s.done_count = (int *)(base + o_cnt);
+    s.obs = (float *)(base + o_obs);
+    s.reward = (double *)(base + o_rew);
+    s.truncated = (uint8_t *)(base + o_trunc);
+    s.done = (uint8_t *)(base + o_done);
+    ctx->d_actions = (int *)(base + o_act);
+    ctx->d_pool = (float *)(base + o_pool);
+
+    rf::EnvConfig &c = ctx->env_cfg;
+    c.n = cfg->n;
+    c.n_actions = cfg->n_actions;
+    for (int i = 0; i < 32; ++i)
+        c.action_set[i] = cfg->action_set[i];
+    c.limit_lo = cfg->limit_lo;
+    c.limit_hi = cfg->limit_hi;
+    c.max_steps = cfg->max_steps;
+    c.diverge_threshold = cfg->diverge_threshold;
+    c.early_end_steps = cfg->early_end_steps;
+    for (int i = 0; i < 4; ++i) {
+        c.mid[i] = cfg->mid[i];
+        c.scale[i] = cfg->scale[i];
+    }
+    c.reward_scale = cfg->reward_scale;
+    c.on_target_span = cfg->on_target_span;
+    c.half_width = cfg->half_width;
+    c.half_height = cfg->half_height;
+    c.tan_half_r = cfg->tan_half_r;
+    for (int i = 0; i < 3; ++i) {
+        c.look_from[i] = cfg->look_from[i];
+        c.cam_u[i] = cfg->cam_u[i];
+        c.cam_v[i] = cfg->cam_v[i];
+        c.cam_w[i] = cfg->cam_w[i];
+    }
+    ctx->env_host = *cfg;
+    ctx->cs = rf::CamStatic{cfg->look_from[0], cfg->look_from[1], cfg->look_from[2], cfg->cam_u[0], cfg->cam_u[1],
+                            cfg->cam_u[2],     cfg->cam_v[0],     cfg->cam_v[1],     cfg->cam_v[2], cfg->lens_radius};
+    // canonical frame -> horizontal = (h2, +0, +0), vertical = (+0, v2, +0): the AXIS kernels apply
+    ctx->env_axis = cfg->look_from[0] == 0.0f && cfg->look_from[1] == 0.0f && cfg->look_from[2] == 0.0f &&
+                    cfg->cam_u[0] == 1.0f && cfg->cam_u[1] == 0.0f && cfg->cam_u[2] == 0.0f &&
+                    cfg->cam_v[0] == 0.0f && cfg->cam_v[1] == 1.0f && cfg->cam_v[2] == 0.0f &&
+                    !signbit(cfg->cam_u[1]) && !signbit(cfg->cam_u[2]) && !signbit(cfg->cam_v[0]) &&
+                    !signbit(cfg->cam_v[2]) && cfg->half_width > 0.0 && cfg->half_height > 0.0;
+    ctx->scene_n = 0; // the env owns the scene arrays from now on
+    ctx->env_ready = true;
+    return RF_OK;
+}
+
+int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
+{
+    RF_REQUIRE(ctx != nullptr && host_states != nullptr && host_obs != nullptr, "rf_env_reset: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_reset: rf_env_configure first");
+    RF_HIP(hipSetDevice(ctx->device));
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    RF_HIP(hipMemcpyAsync(ctx->env.state, host_states, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env, (const int *)nullptr);
+    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+    if (rc != RF_OK)
+        return rc;
+    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const double *)ctx->d_var, 1);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool, float *host_obs,
+                double *host_rewards, uint8_t *host_truncated, int *host_n_reset)
+{
+    RF_REQUIRE(ctx != nullptr && host_actions && host_pool && host_obs && host_rewards && host_truncated,
+               "rf_env_step: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_step: rf_env_configure first");
+    RF_HIP(hipSetDevice(ctx->device));
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    for (int i = 0; i < n; ++i)
+        RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions, "rf_env_step: action %d of env %d out of range",
+                   host_actions[i], i);
+    RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const int *)ctx->d_actions);
+    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+    if (rc != RF_OK)
+        return rc;
+    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const double *)ctx->d_var, 0);
+    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const float *)ctx->d_pool);
+    RF_HIP(hipGetLastError());
+    // the step's flags and rewards are final here; the count sizes the partial render
+    int k = 0;
+    RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    if (k > 0) { // vector_environment.py:137-151: partial render of the envs that just ended
+        rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
+                           ctx->env, (const double *)ctx->d_var);
+        RF_HIP(hipGetLastError());
+    }
+    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    if (host_n_reset)
+        *host_n_reset = k;
+    return RF_OK;
+}
+
+int rf_env_get_states(rf_ctx *ctx, float *host_states)
+{
+    RF_REQUIRE(ctx != nullptr && host_states != nullptr, "rf_env_get_states: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_get_states: rf_env_configure first");
+    RF_HIP(hipSetDevice(ctx->device));
+    RF_HIP(hipMemcpyAsync(host_states, ctx->env.state, (size_t)ctx->env_host.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
 }
 
 } // extern "C"

@@ -1,0 +1,210 @@
+// rf_env.h -- device-resident DiscreteSteps-v0 step.
+//
+// The O(N) numpy glue the reference runs on the host every step --
+//   DiscreteMoveTransformer.transform      environments/state_transformer.py:248-266
+//   TimeLimitEnder | DivergingEnder        environments/episode_ender.py:137-170, :602-628
+//   FastCameras / FastWorlds packing       graphics/camera.py:144-179, graphics/world.py:110-123
+//   NormalizedObserver(DeltaObserver(..))  environments/state_observer.py:232-292, :472-517
+//   Delta + Observation + OnTarget reward  environments/episode_rewarder.py:130-155, :226-292
+//   same-step auto-reset                   environments/vector_environment.py:137-151
+// -- as two small kernels around the render and focus kernels, so that a step moves only the
+// actions and a pool of candidate reset states to the GPU and the observations / rewards /
+// flags back.  Arithmetic follows the numpy expressions operation by operation (float32
+// arrays with Python-float scalars stay float32, the action set is float64, rewards end up
+// float64), so results equal reinfocus_amd/environments/harness.py bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rf {
+
+struct EnvConfig {
+    int n;                    // environments
+    int n_actions;
+    double action_set[32];    // float64 moves (state_transformer.py:246 numpy.asarray(action_set))
+    float limit_lo, limit_hi; // clip limits
+    int max_steps;            // <= 0: no time limit (single-env DiscreteSteps)
+    float diverge_threshold;  // target_radius / 2
+    int early_end_steps;
+    float mid[4], scale[4];   // NormalizedObserver (float32)
+    float reward_scale;       // DeltaRewarder scale (target_radius * 2)
+    float on_target_span;     // OnTargetRewarder span
+    // camera / world packing
+    double half_width, half_height, tan_half_r; // Python floats
+    float look_from[3], cam_u[3], cam_v[3], cam_w[3];
+};
+
+struct EnvState {            // all device arrays, length n unless noted
+    float *state;            // [n][2] target, focus
+    int *steps;              // TimeLimitEnder._steps
+    int *diverging;          // DivergingEnder._diverging_steps
+    float *last_diff;        // DivergingEnder._last_diff
+    float *old_wrapped;      // [n][2] DeltaObserver._old_wrapped_observations
+    float *old_focus;        // DeltaRewarder._old_states
+    // per-step scratch / outputs
+    float *cam_dyn, *rect;   // scene of all n envs
+    float *cam_dyn2, *rect2; // compacted scene of the envs that reset this step
+    int *done_index;         // [n] env index of the r-th reset env
+    int *done_count;         // [1]
+    float *obs;              // [n][4]
+    double *reward;          // [n]
+    uint8_t *truncated;      // [n]
+    uint8_t *done;           // [n] scratch
+};
+
+// camera.py:144-179 + world.py:110-123 for one environment
+__device__ __forceinline__ void pack_scene(const EnvConfig &c, float target, float fp, float *dyn, float *rc)
+{
+    const float a = (float)(c.half_width * (double)fp);   // f32(hw * fp)
+    const float b = (float)(c.half_height * (double)fp);
+    const float h2 = (float)((2.0 * c.half_width) * (double)fp);
+    const float v2 = (float)((2.0 * c.half_height) * (double)fp);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float sum = (a * c.cam_u[k] + b * c.cam_v[k]) + fp * c.cam_w[k]; // numpy.sum, left to right
+        dyn[k] = c.look_from[k] - sum;
+        dyn[3 + k] = h2 * c.cam_u[k];
+        dyn[6 + k] = v2 * c.cam_v[k];
+    }
+    rc[0] = (float)((double)target * c.tan_half_r);
+    rc[1] = -target;
+}
+
+// transformer -> ender.step -> scene of every env (vector_environment.py:124-126 + the
+// update_targets / update_focus_planes of FocusObserver.observe)
+__global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n)
+        return;
+    float target = s.state[2 * e], focus = s.state[2 * e + 1];
+    if (actions) { // step: new = clip(f32(f64(old) + move), lo, hi) on BOTH columns
+        focus = (float)((double)focus + c.action_set[actions[e]]);
+        focus = fminf(fmaxf(focus, c.limit_lo), c.limit_hi);
+        target = fminf(fmaxf(target, c.limit_lo), c.limit_hi);
+        s.state[2 * e] = target;
+        s.state[2 * e + 1] = focus;
+        // enders (episode_ender.py:137-148, :602-607)
+        s.steps[e] += 1;
+        const float diff = fabsf(target - focus);
+        if (diff > s.last_diff[e] + c.diverge_threshold)
+            s.diverging[e] += 1;
+        s.last_diff[e] = diff;
+    } else { // reset of every env
+        s.steps[e] = 0;
+        s.diverging[e] = 0;
+        s.last_diff[e] = fabsf(target - focus);
+    }
+    pack_scene(c, target, focus, s.cam_dyn + 9 * e, s.rect + 2 * e);
+}
+
+__device__ __forceinline__ float normalize1(const EnvConfig &c, int k, float v)
+{
+    return fminf(fmaxf((v - c.mid[k]) / c.scale[k], -1.0f), 1.0f);
+}
+
+// observe -> reward -> done flags (vector_environment.py:128-135); `first` = reset() call
+__global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_values, int first)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n)
+        return;
+    const float target = s.state[2 * e], focus = s.state[2 * e + 1];
+    const float w0 = focus, w1 = (float)focus_values[e];
+    float d0 = 0.0f, d1 = 0.0f;
+    if (!first) {
+        d0 = w0 - s.old_wrapped[2 * e];
+        d1 = w1 - s.old_wrapped[2 * e + 1];
+    }
+    s.old_wrapped[2 * e] = w0;
+    s.old_wrapped[2 * e + 1] = w1;
+    const float o0 = normalize1(c, 0, w0), o1 = normalize1(c, 1, w1), o2 = normalize1(c, 2, d0),
+                o3 = normalize1(c, 3, d1);
+    s.obs[4 * e] = o0;
+    s.obs[4 * e + 1] = o1;
+    s.obs[4 * e + 2] = o2;
+    s.obs[4 * e + 3] = o3;
+    if (first) {
+        s.old_focus[e] = focus;
+        s.truncated[e] = 0;
+        s.done[e] = 0;
+        s.reward[e] = 0.0;
+        return;
+    }
+    // (abs(focus - old) * -1.0 / scale + obs[:, 1]) + ((abs(target - focus) < span) * 1.0 + 0.0)
+    const float moved = fabsf(focus - s.old_focus[e]) * -1.0f / c.reward_scale;
+    s.old_focus[e] = focus;
+    const double on_target = (fabsf(target - focus) < c.on_target_span ? 1.0 : 0.0) * 1.0 + 0.0;
+    s.reward[e] = (double)(moved + o1) + on_target;
+    bool trunc = s.diverging[e] >= c.early_end_steps;
+    if (c.max_steps > 0)
+        trunc = (s.steps[e] >= c.max_steps) || trunc;
+    s.truncated[e] = trunc ? 1 : 0;
+    s.done[e] = trunc ? 1 : 0;
+}
+
+// Ranks the done envs in index order (single block, running offset) and applies the
+// initializer's r-th candidate state to the r-th done env (vector_environment.py:138-142),
+// resets its enders, and packs the compacted scene of the partial render.
+__global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int running;
+    if (threadIdx.x == 0)
+        running = 0;
+    __syncthreads();
+    for (int base = 0; base < c.n; base += 1024) {
+        const int e = base + threadIdx.x;
+        const bool d = e < c.n && s.done[e];
+        const unsigned long long ballot = __ballot(d);
+        const int lane_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+        if ((threadIdx.x & 63) == 0)
+            wave_sum[threadIdx.x >> 6] = __popcll(ballot);
+        __syncthreads();
+        int before = running, total = 0;
+        for (int i = 0; i < 16; ++i) {
+            before += (i < (int)(threadIdx.x >> 6)) ? wave_sum[i] : 0;
+            total += wave_sum[i];
+        }
+        if (d) {
+            const int r = before + lane_rank;
+            const float target = pool[2 * r], focus = pool[2 * r + 1];
+            s.state[2 * e] = target;
+            s.state[2 * e + 1] = focus;
+            s.steps[e] = 0;
+            s.diverging[e] = 0;
+            s.last_diff[e] = fabsf(target - focus);
+            s.done_index[r] = e;
+            pack_scene(c, target, focus, s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *s.done_count = running;
+}
+
+// observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the
+// rewarder's reset (vector_environment.py:144-148)
+__global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *s.done_count)
+        return;
+    const int e = s.done_index[r];
+    const float focus = s.state[2 * e + 1];
+    const float w0 = focus, w1 = (float)focus_values[r];
+    s.old_wrapped[2 * e] = w0;
+    s.old_wrapped[2 * e + 1] = w1;
+    s.obs[4 * e] = normalize1(c, 0, w0);
+    s.obs[4 * e + 1] = normalize1(c, 1, w1);
+    s.obs[4 * e + 2] = normalize1(c, 2, 0.0f);
+    s.obs[4 * e + 3] = normalize1(c, 3, 0.0f);
+    s.old_focus[e] = focus;
+}
+
+} // namespace rf

@@ -73,21 +73,28 @@ class _Ender:
         self._last_diff[indices] = abs(states[:, TARGET] - states[:, FOCUS])
 
 
+def normaliser_constants(ends, max_move, min_focus, max_focus):
+    """mid / scale of NormalizedObserver over DeltaObserver([IndexedElement, Focus], True,
+    [max_move, nan]) -- state_observer.py:166-230, :440-470; everything float32."""
+    lows = np.array([ends[0], min_focus], dtype=np.float32)
+    highs = np.array([ends[1], max_focus], dtype=np.float32)
+    diff = highs - lows
+    diff[0] = max_move
+    low = np.append(lows, -diff)
+    high = np.append(highs, diff)
+    spans = np.vstack([low, high]).astype(np.float32)
+    return np.average(spans, axis=0), np.diff(spans / 2, axis=0).reshape(4)
+
+
 class _Observer:
     """NormalizedObserver(DeltaObserver([IndexedElementObserver, FocusObserver], True,
     [max_move, nan])) -- state_observer.py:166-292, :386-517."""
 
     def __init__(self, num_envs, ends, max_move, focus_observer):
         self._focus = focus_observer
-        lows = np.array([ends[0], focus_observer.single_observation_space.low[0]], dtype=np.float32)
-        highs = np.array([ends[1], focus_observer.single_observation_space.high[0]], dtype=np.float32)
-        diff = highs - lows
-        diff[0] = max_move
-        low = np.append(lows, -diff)
-        high = np.append(highs, diff)
-        spans = np.vstack([low, high]).astype(np.float32)
-        self._mid = np.average(spans, axis=0)
-        self._scale = np.diff(spans / 2, axis=0).reshape(4)
+        self._mid, self._scale = normaliser_constants(
+            ends, max_move, focus_observer.single_observation_space.low[0],
+            focus_observer.single_observation_space.high[0])
         self._old = np.full((num_envs, 2), np.nan, dtype=np.float32)
         self._num_envs = num_envs
         self.single_observation_space = spaces.Box(-np.ones(4, dtype=np.float32), np.ones(4, dtype=np.float32),
@@ -247,3 +254,102 @@ class DiscreteSteps(VectorDiscreteSteps):
         observations = self._observer.observe(self._state)
         reward = self._rewarder.reward(self._state, observations)[0]
         return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
+
+
+class DeviceVectorDiscreteSteps:
+    """VectorDiscreteSteps with the whole step resident on the GPU (rf_env_*, SURVEY.md
+    section 8(f) item 1): same constructor, same reset/step results bit for bit, but a step
+    only uploads the actions and the initializer's candidate states and downloads
+    observations, rewards and flags.  The initializer stays on the host (numpy PCG64DXSM):
+    a copy of the generator proposes num_envs candidate states per step, the device hands
+    row r to the r-th environment that ended, and the real generator then draws exactly the
+    rows that were used -- the same consumption as VectorDiscreteSteps."""
+
+    metadata = {"render_modes": [], "render_fps": 4}
+
+    def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
+                 samples_per_pixel=100, seed=None, device=None, first_state_index=0):
+        import copy
+        import math
+
+        from reinfocus_amd import _native, vision
+        from reinfocus_amd.graphics import camera
+
+        assert render_mode is None, "the device-resident environment has no visualiser"
+        self.render_mode = None
+        self._copy = copy
+        ends = (5.0, 10.0)
+        target_radius = 0.25
+        max_move = 5.0
+        moves = max_move / 2.0 ** np.arange(6)
+        self.num_envs = num_envs
+        self._limits = ends
+        self._initializer = _Initializer(ends, seed)
+        self._action_set = np.concatenate([-moves, [0], moves[::-1]])
+
+        self._ctx = _native.Context(device)
+        min_focus, max_focus = state_observer.cached_focus_extrema(ends, frame_height, samples_per_pixel,
+                                                                   self._ctx.device)
+        box = spaces.Box(min_focus, max_focus, dtype=np.float32)  # float32 rounding of the extrema
+        mid, scale = normaliser_constants(ends, max_move, box.low[0], box.high[0])
+        cams = camera.FastCameras()
+        cfg = _native.EnvConfig()
+        cfg.n = num_envs
+        cfg.n_actions = len(self._action_set)
+        for i, a in enumerate(self._action_set):
+            cfg.action_set[i] = float(a)
+        cfg.limit_lo, cfg.limit_hi = ends
+        cfg.max_steps = max_episode_steps if max_episode_steps else 0
+        cfg.diverge_threshold = target_radius / 2
+        cfg.early_end_steps = 3
+        for i in range(4):
+            cfg.mid[i] = float(mid[i])
+            cfg.scale[i] = float(scale[i])
+        cfg.reward_scale = target_radius * 2
+        cfg.on_target_span = target_radius
+        cfg.half_width = cams._half_width
+        cfg.half_height = cams._half_height
+        cfg.tan_half_r = math.tan(math.radians(20 / 2))
+        for i in range(3):
+            cfg.look_from[i] = float(cams._look_from[i])
+            cfg.cam_u[i] = float(cams._u[i])
+            cfg.cam_v[i] = float(cams._v[i])
+            cfg.cam_w[i] = float(cams._w[i])
+        cfg.lens_radius = float(cams._half_aperture)
+        cfg.frame_height = frame_height
+        cfg.spp = samples_per_pixel
+        cfg.gray_mode = vision.GRAY_MODE
+        self._ctx.seed(num_envs * frame_height * frame_height, 0, first_state_index)
+        self._ctx.env_configure(cfg)
+
+        self.single_action_space = spaces.Discrete(len(self._action_set))
+        self.action_space = spaces.batch_space(self.single_action_space, num_envs)
+        self.single_observation_space = spaces.Box(-np.ones(4, dtype=np.float32), np.ones(4, dtype=np.float32),
+                                                   dtype=np.float32)
+        self.observation_space = spaces.batch_space(self.single_observation_space, num_envs)
+
+    @property
+    def _state(self):
+        return self._ctx.env_states()
+
+    def reset(self, *, seed=None, options=None, state=None):
+        if seed is not None:
+            self._initializer = _Initializer(self._limits, seed)
+        initial = (self._initializer.initialize(self.num_envs) if state is None
+                   else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
+        return self._ctx.env_reset(initial), {}
+
+    def step(self, actions):
+        generator = self._initializer._generator
+        proposal = self._copy.deepcopy(generator)
+        pool = proposal.uniform(self._limits[0], self._limits[1], size=(self.num_envs, 2)).astype(np.float32)
+        observations, rewards, truncated, used = self._ctx.env_step(actions, pool)
+        if used:
+            self._initializer.initialize(used)  # consume exactly the rows that were used
+        return observations, rewards, np.full(self.num_envs, False), truncated, {}
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._ctx.close()

@@ -90,3 +90,35 @@ def test_vector_environment_steps_and_auto_resets(oracle):
         assert np.all(obs[done, 2:] == 0)  # reset observations carry zero deltas
     assert resets > 0
     env.close()
+
+
+@pytest.mark.parametrize("n,height,spp,steps", [(64, 32, 4, 45), (300, 16, 2, 30)])
+def test_device_resident_step_equals_host_harness(n, height, spp, steps):
+    """rf_env_* (transformer, enders, scene packing, normaliser, rewards, auto-reset on the
+    GPU) against the numpy harness: identical observations, rewards, flags and states for
+    the same seeds and actions, step by step, including the partial auto-reset renders."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(num_envs=n, frame_height=height, samples_per_pixel=spp, seed=11, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    o_h, _ = host.reset()
+    o_d, _ = dev.reset()
+    assert o_d.dtype == np.float32 and np.array_equal(o_h, o_d)
+    assert np.array_equal(host._state, dev._state)
+    rng = np.random.default_rng(5)
+    resets = 0
+    for _ in range(steps):
+        actions = rng.integers(0, 13, n)
+        oh, rh, th, ch, _ = host.step(actions)
+        od, rd, td, cd, _ = dev.step(actions)
+        assert np.array_equal(oh, od)
+        assert rd.dtype == np.float64 and np.array_equal(rh, rd)
+        assert np.array_equal(th, td) and np.array_equal(ch, cd)
+        assert np.array_equal(host._state, dev._state)
+        resets += int(ch.sum())
+    assert resets > 0
+    # both initializers consumed the same number of draws
+    assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state
+    host.close()
+    dev.close()
