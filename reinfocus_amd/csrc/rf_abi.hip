@@ -73,6 +73,7 @@ struct rf_ctx {
     rf::CamStatic cs{};
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
+    bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
 
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;
@@ -213,6 +214,8 @@ int rf_create(int device, rf_ctx **out)
     ctx->tab = make_checker_table();
     if (const char *v = getenv("REINFOCUS_RENDER_COOP"))
         ctx->coop = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
+        ctx->focus_quad = v[0] != '0';
 
     std::vector<rf::Mat128> tables;
     if (!rf::h_build_jump_tables(rf::kSeedMats, tables)) {
@@ -474,7 +477,11 @@ namespace {
 // enqueues the focus measure of the first n frames into ctx->d_var (device)
 int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
 {
-    const size_t lds = (((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15;
+    // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
+    const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
+    const bool quad = (w & 3) == 0 && w >= 4 && lds_quad <= 64 * 1024 && ctx->focus_quad;
+    const int band = quad ? rf::kBandQ : rf::kBand;
+    const size_t lds = quad ? lds_quad : ((((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15);
     RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);
     if (n > ctx->focus_cap) {
         RF_HIP(hipStreamSynchronize(ctx->stream));
@@ -490,7 +497,7 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
     RF_HIP(hipMemsetAsync(ctx->d_sums, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
     {
         Timed timed(ctx, &ctx->ev_focus);
-        const int gx = (h + rf::kBand - 1) / rf::kBand;
+        const int gx = (h + band - 1) / band;
         for (int e0 = 0; e0 < n; e0 += 65535) {
             const int ne = (n - e0) < 65535 ? (n - e0) : 65535;
             rf::FocusArgs a;
@@ -500,7 +507,10 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
             a.h = h;
             a.w = w;
             a.gray15 = gray_mode == RF_GRAY_15BIT;
-            hipLaunchKernelGGL(rf::focus_kernel, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
+            if (quad)
+                hipLaunchKernelGGL(rf::focus_kernel_quad, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
+            else
+                hipLaunchKernelGGL(rf::focus_kernel, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
         }
         hipLaunchKernelGGL(rf::focus_finalize, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_sums,
                            ctx->d_var, n, (unsigned long long)h * (unsigned long long)w);

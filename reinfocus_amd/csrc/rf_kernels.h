@@ -395,6 +395,125 @@ __global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// focus_kernel_quad: the same chain for widths that are a multiple of 4, four pixels per
+// thread and dword LDS traffic (the byte-per-thread kernel above spends ~175 lane
+// instructions per pixel, mostly LDS byte reads and index arithmetic).
+//   stage 1  12 B (4 pixels) per lane from HBM -> 4 gray bytes -> one ds_write_b32
+//   stage 2  3 rows x 3 dwords from LDS -> 6 columns sorted once (min3/med3/max3), each of
+//            the 4 medians from 3 neighbouring sorted columns -> one ds_write_b32
+//   stage 3  up / down dwords + 3 centre dwords -> 4 Laplacians, saturate, sums
+// Bands of kBandQ rows per block: halo 4 rows in kBandQ + 4 (12.5 % at 32).
+// ---------------------------------------------------------------------------
+constexpr int kBandQ = 32;
+
+__device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 255u; }
+
+__global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int e = blockIdx.y;
+    const int w = a.w, h = a.h, wq = a.w >> 2;
+    const int r0 = blockIdx.x * kBandQ, r1 = min(r0 + kBandQ, h);
+    const int m0 = max(r0 - 1, 0), m1 = min(r1 + 1, h); // median rows needed
+    const int g0 = max(m0 - 1, 0), g1 = min(m1 + 1, h); // gray rows needed
+
+    uint32_t *gray = reinterpret_cast<uint32_t *>(lds);                              // [(kBandQ+4)][wq]
+    uint32_t *med = reinterpret_cast<uint32_t *>(lds + (size_t)(kBandQ + 4) * w);    // [(kBandQ+2)][wq]
+    const uint8_t *img = a.frames + (size_t)e * h * w * 3;
+
+    {
+        const int quads = (g1 - g0) * wq;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (size_t)g0 * w * 3);
+        for (int q = threadIdx.x; q < quads; q += kBlock) {
+            const uint32_t d0 = src[3 * q + 0], d1 = src[3 * q + 1], d2 = src[3 * q + 2];
+            const uint32_t ga = gray_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, a.gray15);
+            const uint32_t gb = gray_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, a.gray15);
+            const uint32_t gc = gray_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, a.gray15);
+            const uint32_t gd = gray_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, a.gray15);
+            gray[q] = ga | (gb << 8) | (gc << 16) | (gd << 24);
+        }
+    }
+    __syncthreads();
+
+    // median rows [m0, m1): cv2.medianBlur(gray, 3), BORDER_REPLICATE
+    {
+        const int quads = (m1 - m0) * wq;
+        for (int i = threadIdx.x; i < quads; i += kBlock) {
+            const int my = i / wq, q = i - my * wq;
+            const int y = m0 + my;
+            const int rows[3] = {max(y - 1, 0) - g0, y - g0, min(y + 1, h - 1) - g0};
+            uint32_t lo[6], mi[6], hi[6];
+            uint32_t c[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint32_t *row = gray + rows[r] * wq;
+                const uint32_t mid = row[q];
+                const uint32_t left = q > 0 ? row[q - 1] >> 24 : (mid & 255u);         // replicate
+                const uint32_t right = q < wq - 1 ? (row[q + 1] & 255u) : (mid >> 24); // replicate
+                c[r][0] = left;
+                c[r][1] = byte_of(mid, 0);
+                c[r][2] = byte_of(mid, 1);
+                c[r][3] = byte_of(mid, 2);
+                c[r][4] = byte_of(mid, 3);
+                c[r][5] = right;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                lo[j] = min3u(c[0][j], c[1][j], c[2][j]);
+                mi[j] = med3u(c[0][j], c[1][j], c[2][j]);
+                hi[j] = max3u(c[0][j], c[1][j], c[2][j]);
+            }
+            uint32_t out = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t m = med3u(max3u(lo[p], lo[p + 1], lo[p + 2]), med3u(mi[p], mi[p + 1], mi[p + 2]),
+                                         min3u(hi[p], hi[p + 1], hi[p + 2]));
+                out |= m << (8 * p);
+            }
+            med[i] = out;
+        }
+    }
+    __syncthreads();
+
+    // Laplacian rows [r0, r1): cv2.Laplacian(m, CV_8U), ksize 1, BORDER_REFLECT_101
+    uint32_t s1 = 0;
+    unsigned long long s2 = 0;
+    {
+        const int quads = (r1 - r0) * wq;
+        for (int i = threadIdx.x; i < quads; i += kBlock) {
+            const int oy = i / wq, q = i - oy * wq;
+            const int y = r0 + oy;
+            const uint32_t up = med[(reflect101(y - 1, h) - m0) * wq + q];
+            const uint32_t dn = med[(reflect101(y + 1, h) - m0) * wq + q];
+            const uint32_t *row = med + (y - m0) * wq;
+            const uint32_t mid = row[q];
+            // reflect-101: x = -1 -> 1, x = w -> w - 2 (w >= 4 here)
+            const uint32_t left = q > 0 ? row[q - 1] >> 24 : byte_of(mid, 1);
+            const uint32_t right = q < wq - 1 ? (row[q + 1] & 255u) : byte_of(mid, 2);
+            const uint32_t cc[6] = {left, byte_of(mid, 0), byte_of(mid, 1), byte_of(mid, 2), byte_of(mid, 3), right};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int v = (int)(byte_of(up, p) + byte_of(dn, p) + cc[p] + cc[p + 2]) - 4 * (int)cc[p + 1];
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                s1 += (uint32_t)v;
+                s2 += (uint32_t)(v * v);
+            }
+        }
+    }
+
+    unsigned long long t1 = s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t1 += __shfl_down(t1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.sums[2 * e + 0], t1);
+        atomicAdd(&a.sums[2 * e + 1], s2);
+    }
+}
+
 // population variance from exact integer sums: (N*S2 - S1^2) / N^2
 __global__ void focus_finalize(const unsigned long long *sums, double *var, int n, unsigned long long npix)
 {
