@@ -37,8 +37,8 @@ FOCUS_BYTES_PER_PIXEL = 3    # frame read
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--frame", type=int, default=256)
     ap.add_argument("--spp", type=int, default=16)

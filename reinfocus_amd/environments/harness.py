@@ -256,6 +256,46 @@ class DiscreteSteps(VectorDiscreteSteps):
         return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
 
 
+class ContinuousJumps(VectorDiscreteSteps):
+    """The single-environment ContinuousJumps (examples/custom_environments.py:244-339):
+    one continuous action in [-1, 1] jumps the focus plane to the proportional position in
+    [5, 10] unless the jump is shorter than target_radius / 2
+    (ContinuousJumpTransformer, state_transformer.py:66-118); DivergingEnder only; reward =
+    focus value + [stopped] * [on target] (ObservationRewarder + StoppedRewarder *
+    OnTargetRewarder, episode_rewarder.py:210-292, :361-429)."""
+
+    def __init__(self, render_mode=None, **kwargs):
+        super().__init__(num_envs=1, render_mode=render_mode, _diverging_only=True, **kwargs)
+        self._stop_threshold = abs(0.25 / 2.0)
+        self.single_action_space = spaces.Box(-1, 1, dtype=np.float32)
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+        self._old_focus = None
+
+    def reset(self, *, seed=None, options=None, state=None):
+        observations, info = super().reset(seed=seed, options=options, state=state)
+        self._old_focus = self._state[:, FOCUS]  # StoppedRewarder.reset keeps a view
+        return observations[0], info
+
+    def _transform(self, states, actions):
+        new_states = states.copy()
+        actions = (np.asarray(actions, dtype=np.float32).flatten() + 1) / 2.0
+        moved_states = actions * (self._limits[1] - self._limits[0]) + self._limits[0]
+        moved = abs(new_states[:, FOCUS] - moved_states) > self._stop_threshold
+        new_states[moved, FOCUS] = moved_states[moved]
+        return new_states
+
+    def step(self, action):
+        self._state = self._transform(self._state, np.array([action]))
+        self._ender.step(self._state)
+        observations = self._observer.observe(self._state)
+        stopped = (abs(self._state[:, FOCUS] - self._old_focus) < self._stop_threshold) * 1.0
+        self._old_focus = self._state[:, FOCUS]
+        on_target = (abs(self._state[:, TARGET] - self._state[:, FOCUS]) < 0.25) * 1.0 + 0.0
+        reward = (observations[:, 1] + stopped * on_target)[0]
+        return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
+
+
 class DeviceVectorDiscreteSteps:
     """VectorDiscreteSteps with the whole step resident on the GPU (rf_env_*, SURVEY.md
     section 8(f) item 1): same constructor, same reset/step results bit for bit, but a step

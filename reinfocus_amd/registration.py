@@ -4,7 +4,7 @@
 entry_point + vector_entry_point, max_episode_steps=20), and is always available through
 the local make()/make_vec() below, which accept the same arguments as
 gymnasium.make / gymnasium.make_vec(id, num_envs, vectorization_mode="custom", vector_kwargs=...).
-`ContinuousJumps-v0` needs strategy objects outside the hot path and is not provided.
+`ContinuousJumps-v0` (examples/__init__.py:14-18) is the single-environment continuous task.
 """
 
 from reinfocus_amd.environments import harness
@@ -13,6 +13,10 @@ ENTRY_POINTS = {
     "DiscreteSteps-v0": {
         "entry_point": "reinfocus_amd.environments.harness:DiscreteSteps",
         "vector_entry_point": "reinfocus_amd.environments.harness:VectorDiscreteSteps",
+        "max_episode_steps": 20,
+    },
+    "ContinuousJumps-v0": {
+        "entry_point": "reinfocus_amd.environments.harness:ContinuousJumps",
         "max_episode_steps": 20,
     },
 }
@@ -31,14 +35,18 @@ def register_with_gymnasium():
 
 
 def make(env_id, **kwargs):
-    if env_id != "DiscreteSteps-v0":
-        raise KeyError(f"{env_id} is not provided by reinfocus_amd (only DiscreteSteps-v0)")
-    return harness.DiscreteSteps(**kwargs)
+    """Local stand-in for gymnasium.make (without the TimeLimit wrapper gymnasium adds
+    from max_episode_steps)."""
+    if env_id == "DiscreteSteps-v0":
+        return harness.DiscreteSteps(**kwargs)
+    if env_id == "ContinuousJumps-v0":
+        return harness.ContinuousJumps(**kwargs)
+    raise KeyError(f"{env_id} is not provided by reinfocus_amd ({sorted(ENTRY_POINTS)})")
 
 
 def make_vec(env_id, num_envs=1, vectorization_mode="custom", vector_kwargs=None, **kwargs):
     if env_id != "DiscreteSteps-v0":
-        raise KeyError(f"{env_id} is not provided by reinfocus_amd (only DiscreteSteps-v0)")
+        raise KeyError(f"{env_id} has no vector entry point (only DiscreteSteps-v0, examples/__init__.py:6-11)")
     args = {"max_episode_steps": ENTRY_POINTS[env_id]["max_episode_steps"]}
     args.update(vector_kwargs or {})
     args.update(kwargs)

@@ -122,3 +122,20 @@ def test_device_resident_step_equals_host_harness(n, height, spp, steps):
     assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state
     host.close()
     dev.close()
+
+
+def test_continuous_jumps_on_gpu():
+    from reinfocus_amd import registration
+
+    env = registration.make("ContinuousJumps-v0", frame_height=64, samples_per_pixel=8, seed=2, device=0)
+    obs, _ = env.reset()
+    assert obs.shape == (4,) and np.all(np.abs(obs) <= 1)
+    target = env._state[0, 0]
+    # jump onto the target: the focus value rises; staying there earns the +1 bonus
+    action = np.float32((target - 5.0) / 5.0 * 2.0 - 1.0)
+    obs_on, reward_on, term, trunc, _ = env.step(action)
+    obs_stay, reward_stay, *_ = env.step(action)
+    assert not term and not trunc
+    assert obs_on[1] > obs[1] or abs(env._state[0, 1] - target) < 1e-5
+    assert reward_stay == np.float64(obs_stay[1]) + 1.0
+    env.close()

@@ -119,7 +119,36 @@ def test_time_limit(env):
 def test_registration_local_make_vec(monkeypatch, env):
     from reinfocus_amd import registration
 
-    assert set(registration.ENTRY_POINTS) == {"DiscreteSteps-v0"}
+    # examples/__init__.py:6-18
+    assert set(registration.ENTRY_POINTS) == {"DiscreteSteps-v0", "ContinuousJumps-v0"}
     assert registration.ENTRY_POINTS["DiscreteSteps-v0"]["max_episode_steps"] == 20
+    assert "vector_entry_point" not in registration.ENTRY_POINTS["ContinuousJumps-v0"]
     with pytest.raises(KeyError):
         registration.make_vec("ContinuousJumps-v0", 2)
+    with pytest.raises(KeyError):
+        registration.make("NoSuchEnv-v0")
+
+
+def test_continuous_jumps_arithmetic(env):
+    """ContinuousJumpTransformer + ObservationRewarder + StoppedRewarder * OnTargetRewarder."""
+    from reinfocus_amd import registration
+
+    cj = registration.make("ContinuousJumps-v0")
+    assert cj.action_space.shape == (1,) and cj.action_space.low[0] == -1 and cj.action_space.high[0] == 1
+    obs, _ = cj.reset(state=[[7.0, 9.0]])
+    assert obs.shape == (4,) and obs.dtype == np.float32
+    # action 0 -> position 7.5: a real jump, not stopped, not on target (|7 - 7.5| = 0.5)
+    obs, reward, terminated, truncated, _ = cj.step(np.float32(0.0))
+    assert np.array_equal(cj._state, np.array([[7.0, 7.5]], dtype=np.float32))
+    assert reward == np.float64(obs[1]) and not terminated and not truncated
+    # action -0.38 -> 6.55?  |7.5 - 6.55| > 0.125: jump; on target? |7 - 6.55| = 0.45: no
+    obs, reward, *_ = cj.step(np.float32(-0.38))
+    assert abs(cj._state[0, 1] - 6.55) < 1e-6 and reward == np.float64(obs[1])
+    # a jump of less than 0.125 is suppressed: stopped, and now |7 - 6.55| >= 0.25 -> reward = fv
+    obs, reward, *_ = cj.step(np.float32(-0.36))
+    assert abs(cj._state[0, 1] - 6.55) < 1e-6 and reward == np.float64(obs[1])
+    # jump onto the target, then stay: stopped * on_target adds 1
+    cj.step(np.float32(-0.2))
+    assert abs(cj._state[0, 1] - 7.0) < 1e-6
+    obs, reward, *_ = cj.step(np.float32(-0.21))
+    assert abs(cj._state[0, 1] - 7.0) < 1e-6 and reward == np.float64(obs[1]) + 1.0
