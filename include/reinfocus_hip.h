@@ -118,6 +118,22 @@ int rf_timing(rf_ctx *ctx, int enable);
 int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches,
                    double *focus_ms, uint64_t *focus_launches);
 
+/* ---- general renderer ------------------------------------
+ * Renders n environments of spheres and z-aligned rectangles seen through per-environment
+ * cameras, with up to 50 diffuse bounces per sample, into the ctx's frame buffer
+ * (uint8[n][h][w][3]) and optionally to host_out.  As the reference does for every call
+ * (render.py:115) the RNG states [0, n*h*w) are re-created from seed 0 first.
+ *   cameras float64[n][19]: lower_left, horizontal, vertical, origin, u, v (3 each), lens
+ *           radius -- the numpy.hstack row of camera.Cameras (camera.py:63-83)
+ *   params  float32[n][most][width], types int32[n][most] (0 sphere, 1 rectangle),
+ *           sizes int32[n]: world.Worlds (world.py:30-65); a sphere is {x, y, z, r, fx, fy}
+ *           (sphere.py:14-19), a rectangle {x_min, x_max, y_min, y_max, z, fx, fy}
+ *           (rectangle.py:12-19)
+ * Replaces: render.render (graphics/render.py:88-119) and kernel device_render (:31-85). */
+int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *cameras,
+                      const float *params, const int32_t *types, const int32_t *sizes, int most,
+                      int width, uint8_t *host_out);
+
 /* ---- device-resident DiscreteSteps-v0 step ------------
  * The per-step numpy glue of the reference's vector environment runs on the GPU around
  * the render and focus kernels; a step uploads the actions and a pool of candidate reset

@@ -88,6 +88,37 @@ def render_case(name, targets, focus, h, w, spp, r_size=20, passes=1):
     print(name, "done", flush=True)
 
 
+def general_case(name, cams, env_shapes, h, w, spp):
+    cameras = r.pack_general_cameras(cams)
+    world = r.pack_worlds_general(env_shapes)
+    st = r.seed_states(len(env_shapes) * h * w, 0)
+    frames = r.render_general(cameras, world, h, w, spp, st)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), cameras=cameras, params=world[0], types=world[1],
+                        sizes=world[2], h=h, w=w, spp=spp, frames=frames, states_after=states_array(st))
+    print(name, "done", flush=True)
+
+
+def general_vectors():
+    tan15 = __import__("math").tan(__import__("math").radians(15))
+    tan10 = __import__("math").tan(__import__("math").radians(10))
+    one_sphere = [r.sphere_shape((0, 0, -10.0), 10.0 * tan10)]
+    two_sphere = [r.sphere_shape((-20.0 * tan15, 0, -20.0), 20.0 * tan10), r.sphere_shape((5.0 * tan15, 0, -5.0), 5.0 * tan10)]
+    one_rect = [r.rectangle_shape((-10 * tan10, 10 * tan10), (-10 * tan10, 10 * tan10), -10.0)]
+    mixed = [r.sphere_shape((-5.0 * tan15, 0, -5.0), 5.0 * tan10),
+             r.rectangle_shape((10 * tan15 - 10 * tan10, 10 * tan15 + 10 * tan10), (-10 * tan10, 10 * tan10), -10.0)]
+    facing = [r.rectangle_shape((-3, 3), (-3, 3), -6.0, (4, 4)), r.sphere_shape((0, 0, -4.0), 1.0, (8, 8))]
+    cams = [r.make_gpu_camera(), r.make_gpu_camera(focus_distance=5.0),
+            r.make_gpu_camera(aperture=0.5, focus_distance=8.0, vfov=40, aspect_ratio=1.5),
+            r.make_gpu_camera(look_from=(0.5, 0.3, 1.0), look_at=(0, 0, -6), focus_distance=6.0, aperture=0.2)]
+    general_case("general_small", cams, [one_sphere, two_sphere, mixed, facing], 12, 18, 3)
+    general_case("general_rect", [r.make_gpu_camera()], [one_rect], 16, 16, 4)
+    # single-function known answers
+    hit = r.sphere_hit(r.sphere_shape((0, 0, 0), 1, (4, 8))[0], r.v3(10, 0, 0), r.v3(-1, 0, 0), r.f32(0), r.f32(100))
+    flat = [1.0] + list(hit[0]) + list(hit[1]) + [hit[2]] + list(hit[3]) + list(hit[4]) + [hit[5]]
+    np.savez(os.path.join(OUT, "general_fns.npz"), sphere_hit=np.array(flat, dtype=np.float32),
+             cameras=r.pack_general_cameras(cams))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng_vectors()
@@ -103,6 +134,7 @@ def main():
     render_case("render_cfg1", [7.5], [6.0], 64, 64, 1)
     # wider coverage of the rejection loops / edge pixels
     render_case("render_mid", [5.0, 6.6, 8.3, 10.0], [10.0, 6.6, 7.9, 5.0], 32, 32, 8)
+    general_vectors()
 
 
 if __name__ == "__main__":

@@ -65,6 +65,16 @@ def lib():
         L.orc_scatter.argtypes = [p, p, p, p, p]
         L.orc_fast_find_colour.argtypes = [p, p, p, p, p]
         L.orc_render.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int]
+        L.orc_sphere_hit.argtypes = [p, p, p, ctypes.c_float, ctypes.c_float, p]
+        L.orc_sphere_hit.restype = ctypes.c_int
+        L.orc_sphere_uv.argtypes = [p, p]
+        L.orc_rectangle_hit.argtypes = [p, p, p, ctypes.c_float, ctypes.c_float, p]
+        L.orc_rectangle_hit.restype = ctypes.c_int
+        L.orc_world_hit.argtypes = [p, p, ctypes.c_int, ctypes.c_int, p, p, ctypes.c_float, ctypes.c_float, p]
+        L.orc_world_hit.restype = ctypes.c_int
+        L.orc_find_colour.argtypes = [p, p, ctypes.c_int, ctypes.c_int, p, p, p, p]
+        L.orc_render_general.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p,
+                                                                   ctypes.c_int]
         L.orc_gray.argtypes = [p, ctypes.c_int, ctypes.c_int, ctypes.c_int, p]
         L.orc_median3.argtypes = [p, ctypes.c_int, ctypes.c_int, p]
         L.orc_laplacian_u8.argtypes = [p, ctypes.c_int, ctypes.c_int, p]
@@ -179,6 +189,60 @@ def render(cam_dyn, rect, h, w, spp, states, cs=None, n_threads=1):
     frames = np.zeros((n, h, w, 3), dtype=np.uint8)
     lib().orc_render(_ptr(frames), n, h, w, spp, _ptr(cam_dyn), _ptr(rect), ctypes.byref(cs),
                      _ptr(states), n_threads)
+    return frames
+
+
+def sphere_hit(sphere, origin, direction, t_min, t_max):
+    sphere, origin, direction = _f32(sphere), _f32(origin), _f32(direction)
+    rec = np.zeros(13, dtype=np.float32)
+    hit = lib().orc_sphere_hit(_ptr(sphere), _ptr(origin), _ptr(direction), t_min, t_max, _ptr(rec))
+    return bool(hit), rec
+
+
+def sphere_uv(point):
+    point = _f32(point)
+    out = np.zeros(2, dtype=np.float32)
+    lib().orc_sphere_uv(_ptr(point), _ptr(out))
+    return out
+
+
+def rectangle_hit(rect, origin, direction, t_min, t_max):
+    rect, origin, direction = _f32(rect), _f32(origin), _f32(direction)
+    rec = np.zeros(13, dtype=np.float32)
+    hit = lib().orc_rectangle_hit(_ptr(rect), _ptr(origin), _ptr(direction), t_min, t_max, _ptr(rec))
+    return bool(hit), rec
+
+
+def world_hit(params, types, origin, direction, t_min, t_max):
+    """params float32[n_shapes, width], types int32[n_shapes] of one environment."""
+    params, origin, direction = _f32(params), _f32(origin), _f32(direction)
+    types = np.ascontiguousarray(types, dtype=np.int32)
+    rec = np.zeros(13, dtype=np.float32)
+    hit = lib().orc_world_hit(_ptr(params), _ptr(types), params.shape[0], params.shape[1], _ptr(origin),
+                              _ptr(direction), t_min, t_max, _ptr(rec))
+    return bool(hit), rec
+
+
+def find_colour(params, types, origin, direction, state):
+    params, origin, direction = _f32(params), _f32(origin), _f32(direction)
+    types = np.ascontiguousarray(types, dtype=np.int32)
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_find_colour(_ptr(params), _ptr(types), params.shape[0], params.shape[1], _ptr(origin),
+                          _ptr(direction), _ptr(state), _ptr(out))
+    return out
+
+
+def render_general(cameras, params, types, sizes, h, w, spp, states, n_threads=1):
+    """render.py:31-85 device_render; cameras float64[n,19], params float32[n,most,width]."""
+    cameras = np.ascontiguousarray(cameras, dtype=np.float64)
+    params = _f32(params)
+    types = np.ascontiguousarray(types, dtype=np.int32)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    n, most, width = params.shape
+    assert cameras.shape == (n, 19) and types.shape == (n, most) and sizes.shape == (n,)
+    frames = np.zeros((n, h, w, 3), dtype=np.uint8)
+    lib().orc_render_general(_ptr(frames), n, h, w, spp, _ptr(cameras), _ptr(params), _ptr(types), _ptr(sizes),
+                             most, width, _ptr(states), n_threads)
     return frames
 
 

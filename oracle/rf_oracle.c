@@ -302,6 +302,188 @@ void orc_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_
 }
 
 /* ------------------------------------------------------------------------ */
+/* general renderer: render.py:31-119, world.py:126-167, physics.py:95-145,  */
+/* sphere.py:40-117, rectangle.py:49-99                                      */
+/* ------------------------------------------------------------------------ */
+
+static inline float dot3(const float a[3], const float b[3])
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; /* vector.py:254-265, f32 */
+}
+
+/* sphere.py:106-117 uv: (atan2(-z, x) + pi) / pi, acos(-y) / pi in float64 (math.* on
+ * f32 arguments), cast to f32.  acos outside [-1, 1] is NaN (device semantics). */
+void orc_sphere_uv(const float point[3], float uv[2])
+{
+    uv[0] = (float)((atan2(-(double)point[2], (double)point[0]) + ORC_PI) / ORC_PI);
+    uv[1] = (float)(acos(-(double)point[1]) / ORC_PI);
+}
+
+/* sphere.py:40-103 hit.  sphere = {x, y, z, r, fx, fy}.  a, b, c, discriminant in f32;
+ * sqrtd = math.sqrt -> f64; root = (-b -/+ sqrtd) / a in f64; p = o + f32(d * root);
+ * n = (p - centre) * f32(1.0 / r). */
+int orc_sphere_hit(const float *sp, const float origin[3], const float direction[3],
+                   float t_min, float t_max, float rec[13])
+{
+    memset(rec, 0, 13 * sizeof(float));
+    const float centre[3] = {sp[0], sp[1], sp[2]};
+    const float radius = sp[3];
+    float oc[3];
+    for (int k = 0; k < 3; ++k)
+        oc[k] = origin[k] - centre[k];
+    const float a = dot3(direction, direction);
+    const float b = dot3(oc, direction);
+    const float c = dot3(oc, oc) - radius * radius;
+    const float disc = b * b - a * c;
+    if (disc < 0)
+        return 0;
+    const double sqrtd = sqrt((double)disc);
+    double root = (-(double)b - sqrtd) / (double)a;
+    if (root < (double)t_min || (double)t_max < root) {
+        root = (-(double)b + sqrtd) / (double)a;
+        if (root < (double)t_min || (double)t_max < root)
+            return 0;
+    }
+    float p[3], n[3];
+    const float inv_r = (float)(1.0 / (double)radius);
+    for (int k = 0; k < 3; ++k)
+        p[k] = add2(origin[k], (float)((double)direction[k] * root));
+    for (int k = 0; k < 3; ++k)
+        n[k] = (p[k] - centre[k]) * inv_r;
+    rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
+    rec[3] = n[0]; rec[4] = n[1]; rec[5] = n[2];
+    rec[6] = (float)root;
+    orc_sphere_uv(n, &rec[7]);
+    rec[9] = sp[4];
+    rec[10] = sp[5];
+    rec[11] = 0.0f; /* shape.SPHERE */
+    return 1;
+}
+
+/* rectangle.py:49-99 hit.  rect = {x_min, x_max, y_min, y_max, z, fx, fy}. */
+int orc_rectangle_hit(const float *rp, const float origin[3], const float direction[3],
+                      float t_min, float t_max, float rec[13])
+{
+    memset(rec, 0, 13 * sizeof(float));
+    const float t = (rp[4] - origin[2]) / direction[2];
+    if (t < t_min || t > t_max)
+        return 0;
+    float p[3];
+    for (int k = 0; k < 3; ++k)
+        p[k] = add2(origin[k], direction[k] * t);
+    if (p[0] < rp[0] || p[0] > rp[1] || p[1] < rp[2] || p[1] > rp[3])
+        return 0;
+    rec[0] = p[0]; rec[1] = p[1]; rec[2] = p[2];
+    rec[3] = 0.0f; rec[4] = 0.0f; rec[5] = 1.0f;
+    rec[6] = t;
+    orc_uv(p, rp[0], rp[1], rp[2], rp[3], &rec[7]);
+    rec[9] = rp[5];
+    rec[10] = rp[6];
+    rec[11] = 1.0f; /* shape.RECTANGLE */
+    return 1;
+}
+
+/* world.py:126-167 hit: closest hit over the env's shapes (t_max shrinks). */
+int orc_world_hit(const float *params, const int32_t *types, int n_shapes, int width,
+                  const float origin[3], const float direction[3], float t_min, float t_max,
+                  float rec[13])
+{
+    int hit_anything = 0;
+    float closest = t_max;
+    float tmp[13];
+    memset(rec, 0, 13 * sizeof(float));
+    for (int i = 0; i < n_shapes; ++i) {
+        const float *p = params + (long)i * width;
+        const int h = types[i] == 0 ? orc_sphere_hit(p, origin, direction, t_min, closest, tmp)
+                                    : orc_rectangle_hit(p, origin, direction, t_min, closest, tmp);
+        if (h) {
+            hit_anything = 1;
+            closest = tmp[6];
+            memcpy(rec, tmp, sizeof(tmp));
+        }
+    }
+    return hit_anything;
+}
+
+/* physics.py:95-145 find_colour: up to 50 bounces, black afterwards. */
+void orc_find_colour(const float *params, const int32_t *types, int n_shapes, int width,
+                     const float origin[3], const float direction[3], orc_state *st, float colour[3])
+{
+    float o[3] = {origin[0], origin[1], origin[2]};
+    float d[3] = {direction[0], direction[1], direction[2]};
+    float att[3] = {1.0f, 1.0f, 1.0f};
+    float rec[13];
+    for (int bounce = 0; bounce < 50; ++bounce) {
+        if (orc_world_hit(params, types, n_shapes, width, o, d, 0.001f, 1000000.0f, rec)) {
+            float a2[3];
+            orc_scatter(rec, st, o, d, a2);
+            for (int k = 0; k < 3; ++k)
+                att[k] = att[k] * a2[k];
+        } else {
+            const float len = (float)sqrt((double)squared_length(d));
+            const float inv = 1.0f / len;
+            const float ud1 = d[1] * inv;
+            const double t = 0.5 * ((double)ud1 + 1.0);
+            static const float sky[3] = {0.5f, 0.7f, 1.0f};
+            for (int k = 0; k < 3; ++k) {
+                const float white = (float)((double)1.0f * (1.0 - t));
+                const float blue = (float)((double)sky[k] * t);
+                colour[k] = add2(white, blue) * att[k];
+            }
+            return;
+        }
+    }
+    colour[0] = colour[1] = colour[2] = 0.0f;
+}
+
+/* render.py:31-85 device_render with camera.from_cameras (camera.py:255-281): the camera
+ * row is float64[19]; every vector is cast to f32, the lens radius stays f64. */
+void orc_render_general(uint8_t *frames, int n, int h, int w, int spp, const double *cameras,
+                        const float *params, const int32_t *types, const int32_t *sizes, int most,
+                        int width, orc_state *states, int n_threads)
+{
+    const float scale = (float)(255.0 / (double)spp);
+    const long rows = (long)n * h;
+    if (n_threads < 1)
+        n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+    for (long row = 0; row < rows; ++row) {
+        const int e = (int)(row / h), y = (int)(row % h);
+        const double *cam = cameras + (long)e * 19;
+        float dyn[9];
+        orc_cam_static cs;
+        for (int k = 0; k < 9; ++k)
+            dyn[k] = (float)cam[k];
+        for (int k = 0; k < 3; ++k) {
+            cs.origin[k] = (float)cam[9 + k];
+            cs.u[k] = (float)cam[12 + k];
+            cs.v[k] = (float)cam[15 + k];
+        }
+        cs.lens_radius = cam[18];
+        for (int x = 0; x < w; ++x) {
+            const long pix = ((long)e * h + y) * w + x;
+            orc_state st = states[pix];
+            float colour[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < spp; ++k) {
+                float xi = orc_uniform_float(&st);
+                float s = (float)(((double)x + (double)xi) / (double)w);
+                float yi = orc_uniform_float(&st);
+                float t = (float)(((double)y + (double)yi) / (double)h);
+                float ro[3], rd[3], sample[3];
+                orc_get_ray(dyn, &cs, s, t, &st, ro, rd);
+                orc_find_colour(params + ((long)e * most) * width, types + (long)e * most, sizes[e], width, ro, rd,
+                                &st, sample);
+                for (int c = 0; c < 3; ++c)
+                    colour[c] = add2(colour[c], sample[c]);
+            }
+            for (int c = 0; c < 3; ++c)
+                frames[pix * 3 + c] = (uint8_t)(colour[c] * scale);
+            states[pix] = st;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* vision.py:11-39 -- OpenCV (opencv-python ~=4.9.0.80) restated            */
 /* ------------------------------------------------------------------------ */
 

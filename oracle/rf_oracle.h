@@ -67,6 +67,22 @@ void orc_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_
                 const float *rect, const orc_cam_static *cs, orc_state *states,
                 int n_threads);
 
+/* ---- general renderer: spheres + rectangles, 50-bounce find_colour ---- */
+int orc_sphere_hit(const float *sphere, const float origin[3], const float direction[3],
+                   float t_min, float t_max, float rec[13]);
+void orc_sphere_uv(const float point[3], float uv[2]);
+int orc_rectangle_hit(const float *rect, const float origin[3], const float direction[3],
+                      float t_min, float t_max, float rec[13]);
+int orc_world_hit(const float *params, const int32_t *types, int n_shapes, int width,
+                  const float origin[3], const float direction[3], float t_min, float t_max,
+                  float rec[13]);
+void orc_find_colour(const float *params, const int32_t *types, int n_shapes, int width,
+                     const float origin[3], const float direction[3], orc_state *st, float colour[3]);
+void orc_render_general(uint8_t *frames, int n, int h, int w, int spp, const double *cameras /*[n][19]*/,
+                        const float *params /*[n][most][width]*/, const int32_t *types /*[n][most]*/,
+                        const int32_t *sizes /*[n]*/, int most, int width, orc_state *states,
+                        int n_threads);
+
 /* ---- vision.py:11-39 (OpenCV 4.9 semantics restated) ---- */
 void orc_gray(const uint8_t *rgb, int h, int w, int gray_mode, uint8_t *gray);
 void orc_median3(const uint8_t *src, int h, int w, uint8_t *dst);

@@ -42,6 +42,7 @@ SYMBOLS = (
     "rf_synchronize",
     "rf_timing",
     "rf_timing_read",
+    "rf_render_general",
     "rf_env_configure",
     "rf_env_reset",
     "rf_env_step",
@@ -118,6 +119,7 @@ def load():
     lib.rf_timing.argtypes = [vp, i32]
     lib.rf_timing_read.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(u64), ctypes.POINTER(dbl),
                                    ctypes.POINTER(u64)]
+    lib.rf_render_general.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]
     lib.rf_env_configure.argtypes = [vp, ctypes.POINTER(EnvConfig)]
     lib.rf_env_reset.argtypes = [vp, vp, vp]
     lib.rf_env_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
@@ -232,6 +234,22 @@ class Context:
     def step(self, n, h, w, spp, gray_mode=GRAY_15BIT):
         out = np.empty(n, dtype=np.float64)
         _check(self._lib.rf_step(self._h, n, h, w, spp, gray_mode, _ptr(out)))
+        return out
+
+    # --- general renderer ------------------------------------------------------------------
+    def render_general(self, cameras, params, types, sizes, h, w, spp):
+        cameras = np.ascontiguousarray(cameras, dtype=np.float64)
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        types = np.ascontiguousarray(types, dtype=np.int32)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        n, most, width = params.shape
+        assert cameras.shape == (n, 19) and types.shape == (n, most) and sizes.shape == (n,)
+        if width < 7:  # the kernel reads up to 7 parameters per shape
+            params = np.ascontiguousarray(np.pad(params, ((0, 0), (0, 0), (0, 7 - width))))
+            width = 7
+        out = np.empty((n, h, w, 3), dtype=np.uint8)
+        _check(self._lib.rf_render_general(self._h, n, h, w, spp, _ptr(cameras), _ptr(params), _ptr(types),
+                                           _ptr(sizes), most, width, _ptr(out)))
         return out
 
     # --- device-resident env step ----------------------------------------------------------

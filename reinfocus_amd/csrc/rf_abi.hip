@@ -585,6 +585,80 @@ int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches, do
     return rc;
 }
 
+/* ---- general renderer ---------------------------------------------------------------------- */
+
+int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *cameras, const float *params,
+                      const int32_t *types, const int32_t *sizes, int most, int width, uint8_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr && cameras && params && types && sizes, "rf_render_general: NULL argument");
+    RF_REQUIRE(n > 0 && h > 0 && w > 0 && spp > 0 && most > 0 && width >= 7, "rf_render_general: bad sizes");
+    RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render_general: frame too large");
+    for (int e = 0; e < n; ++e) {
+        RF_REQUIRE(sizes[e] >= 0 && sizes[e] <= most, "rf_render_general: sizes[%d]=%d exceeds %d", e, sizes[e], most);
+        for (int i = 0; i < sizes[e]; ++i)
+            RF_REQUIRE(types[(size_t)e * most + i] == 0 || types[(size_t)e * most + i] == 1,
+                       "rf_render_general: unknown shape type");
+    }
+    int rc = rf_seed(ctx, (uint64_t)n * h * w, 0, 0); // render.py:115: fresh seed-0 states per call
+    if (rc != RF_OK)
+        return rc;
+    rc = ensure_frames(ctx, n, h, w);
+    if (rc != RF_OK)
+        return rc;
+    const size_t b_cam = (size_t)n * 19 * sizeof(double), b_par = (size_t)n * most * width * sizeof(float),
+                 b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t);
+    const size_t o_par = (b_cam + 255) & ~(size_t)255, o_typ = o_par + ((b_par + 255) & ~(size_t)255),
+                 o_siz = o_typ + ((b_typ + 255) & ~(size_t)255), total = o_siz + b_siz;
+    char *scratch = nullptr;
+    RF_HIP(hipMalloc((void **)&scratch, total));
+    hipError_t he = hipMemcpyAsync(scratch, cameras, b_cam, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_typ, types, b_typ, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_siz, sizes, b_siz, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) {
+        rf::GeneralArgs a;
+        a.frames = ctx->d_frames;
+        a.states = ctx->d_states;
+        a.cameras = (const double *)scratch;
+        a.params = (const float *)(scratch + o_par);
+        a.types = (const int32_t *)(scratch + o_typ);
+        a.sizes = (const int32_t *)(scratch + o_siz);
+        a.n = n;
+        a.h = h;
+        a.w = w;
+        a.spp = spp;
+        a.hw = h * w;
+        a.most = most;
+        a.width = width;
+        a.scale = (float)(255.0 / (double)spp);
+        const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
+        Timed timed(ctx, &ctx->ev_render);
+        for (int e0 = 0; e0 < n && he == hipSuccess; e0 += 65535) {
+            const int ne = (n - e0) < 65535 ? (n - e0) : 65535;
+            rf::GeneralArgs b = a;
+            b.frames = a.frames + (size_t)e0 * a.hw * 3;
+            b.states = a.states + (size_t)e0 * a.hw;
+            b.cameras = a.cameras + (size_t)e0 * 19;
+            b.params = a.params + (size_t)e0 * most * width;
+            b.types = a.types + (size_t)e0 * most;
+            b.sizes = a.sizes + e0;
+            b.n = ne;
+            hipLaunchKernelGGL(rf::render_general_kernel, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
+            he = hipGetLastError();
+        }
+    }
+    if (he == hipSuccess)
+        he = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(scratch);
+    if (he != hipSuccess) {
+        set_err("rf_render_general: %s", hipGetErrorString(he));
+        return RF_ERR_HIP;
+    }
+    if (host_out)
+        return rf_get_frames(ctx, 0, n, host_out);
+    return RF_OK;
+}
+
 /* ---- device-resident env step ------------------------------------------------------------ */
 
 int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)

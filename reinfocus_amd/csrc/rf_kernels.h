@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "rf_general.h"
 #include "rf_math.h"
 
 namespace rf {
@@ -262,6 +263,43 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
         dst[1] = g8;
         dst[2] = b8;
     }
+}
+
+// ---------------------------------------------------------------------------
+// render_general_kernel: device_render (graphics/render.py:31-85) for worlds of spheres and
+// rectangles with per-environment cameras; literal arithmetic (rf_general.h), one thread
+// per pixel, lanes along x.  Not the benchmarked path: no specialisations.
+// ---------------------------------------------------------------------------
+struct GeneralArgs {
+    uint8_t *frames;
+    ulonglong2 *states;
+    const double *cameras;  // [n][19]
+    const float *params;    // [n][most][width]
+    const int32_t *types;   // [n][most]
+    const int32_t *sizes;   // [n]
+    int n, h, w, spp, hw, most, width;
+    float scale;
+};
+
+__global__ __launch_bounds__(kBlock) void render_general_kernel(GeneralArgs a)
+{
+    const int e = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.hw)
+        return;
+    const int y = p / a.w, x = p - y * a.w;
+    const size_t pix = (size_t)e * a.hw + p;
+    const ulonglong2 st = a.states[pix];
+    Rng g = rng_load(st.x, st.y);
+    float cr, cg, cb;
+    render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras + (size_t)e * 19,
+                         a.params + ((size_t)e * a.most) * a.width, a.types + (size_t)e * a.most, a.sizes[e],
+                         a.width, cr, cg, cb);
+    a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
+    uint8_t *dst = a.frames + pix * 3;
+    dst[0] = (uint8_t)(cr * a.scale);
+    dst[1] = (uint8_t)(cg * a.scale);
+    dst[2] = (uint8_t)(cb * a.scale);
 }
 
 // ---------------------------------------------------------------------------

@@ -125,3 +125,17 @@ class FastRenderer:
         frames = DeviceFrames(self, grid_shape + (3,), self._generation)
         self._last_frames = weakref.ref(frames)
         return frames
+
+
+def render(world_data, cameras, frame_shape=(300, 600), block_shape=(1, 16, 16), samples_per_pixel=100,
+           device=None):
+    """render.render (render.py:88-119): ray traced images uint8[N, H, W, 3] of world_data
+    (world.Worlds) seen by cameras (camera.Cameras); fresh seed-0 RNG states per call, up
+    to 50 bounces per sample.  block_shape is accepted for signature parity."""
+    parameters, types, sizes = world_data.device_data()
+    ctx = _native.Context(device)
+    try:
+        return ctx.render_general(cameras.device_data(), parameters, types, sizes, frame_shape[0], frame_shape[1],
+                                  samples_per_pixel)
+    finally:
+        ctx.close()

@@ -23,3 +23,27 @@ class FastWorlds(device_data.DeviceData):
         targets = np.asarray(data, dtype=np.float32)
         half = (targets.astype(np.float64) * math.tan(math.radians(self._r_size / 2))).astype(np.float32)
         return np.ascontiguousarray(np.stack([half, -targets], axis=1), dtype=np.float32)
+
+
+class Worlds:
+    """world.Worlds (world.py:27-82): per-environment shape lists packed as
+    (parameters float32[n, most, width], types int32[n, most], sizes int32[n])."""
+
+    def __init__(self, *env_shapes):
+        sizes = np.array([len(shapes) for shapes in env_shapes], dtype=np.int32)
+        self._num_envs = len(env_shapes)
+        most = int(max(sizes))
+        width = max(max(len(s.parameters) for s in shapes) for shapes in env_shapes)
+        parameters = np.zeros((self._num_envs, most, width), dtype=np.float32)
+        types = np.zeros((self._num_envs, most), dtype=np.int32)
+        for e, shapes in enumerate(env_shapes):
+            for i, s in enumerate(shapes):
+                parameters[e, i, : len(s.parameters)] = s.parameters
+                types[e, i] = s.shape_type
+        self._data = (parameters, types, sizes)
+
+    def __len__(self):
+        return self._num_envs
+
+    def device_data(self):
+        return self._data

@@ -8,6 +8,7 @@
 
 #include "../../reinfocus_amd/csrc/rf_math.h"
 #include "../../reinfocus_amd/csrc/rf_jump.h"
+#include "../../reinfocus_amd/csrc/rf_general.h"
 
 using namespace rf;
 
@@ -54,6 +55,28 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
                 frames[pix * 3 + 2] = (uint8_t)(cb * scale);
             }
     }
+    return 0;
+}
+
+// the general renderer's per-pixel arithmetic (rf_general.h) on the host
+int hs_render_general(uint8_t *frames, int n, int h, int w, int spp, const double *cameras, const float *params,
+                      const int32_t *types, const int32_t *sizes, int most, int width, uint64_t *states)
+{
+    const float scale = (float)(255.0 / (double)spp);
+    for (int e = 0; e < n; ++e)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const long pix = ((long)e * h + y) * w + x;
+                Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
+                float cr, cg, cb;
+                render_pixel_general(g, x, y, h, w, spp, cameras + (long)e * 19, params + ((long)e * most) * width,
+                                     types + (long)e * most, sizes[e], width, cr, cg, cb);
+                states[2 * pix] = rng_s0(g);
+                states[2 * pix + 1] = rng_s1(g);
+                frames[pix * 3 + 0] = (uint8_t)(cr * scale);
+                frames[pix * 3 + 1] = (uint8_t)(cg * scale);
+                frames[pix * 3 + 2] = (uint8_t)(cb * scale);
+            }
     return 0;
 }
 

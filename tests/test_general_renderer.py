@@ -1,0 +1,210 @@
+"""The general renderer on the CPU side: every known answer
+the reference's tests hold for spheres, rectangles, worlds, cameras, find_colour and
+render (tests/graphics/{sphere,rectangle,world,camera,physics,render,shape_factory}_test.py),
+asserted against the oracle and the host mirrors; the numpy-1.26 golden frames; and the
+kernel's arithmetic (rf_general.h compiled for the host) against the oracle."""
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from numpy import testing
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SPHERE, RECTANGLE = 0, 1
+
+
+def _flatten(hit, rec):
+    """numba_test_utils.flatten_hit_result order: hit, p, n, t, uv, uf, m."""
+    return np.concatenate([[float(hit)], rec[:12]])
+
+
+# --- sphere_test.py / rectangle_test.py / world_test.py -------------------------------------
+
+
+def test_shape_constructors():
+    from reinfocus_amd.graphics import shape
+
+    testing.assert_allclose(shape.sphere(shape.v3f(1, 2, 3), 4, shape.v2f(5, 6)).parameters, [1, 2, 3, 4, 5, 6])
+    testing.assert_allclose(shape.rectangle(shape.v2f(0, 1), shape.v2f(2, 3), 4, shape.v2f(5, 6)).parameters,
+                            [0, 1, 2, 3, 4, 5, 6])
+    assert shape.sphere(shape.v3f(), 1).shape_type == shape.SPHERE == 0
+    assert shape.rectangle(shape.v2f(), shape.v2f(), 0).shape_type == shape.RECTANGLE == 1
+
+
+def test_sphere_hit_and_uv(oracle):
+    """sphere_test.py:30-66 (exact 13-vector) and :69-90."""
+    hit, rec = oracle.sphere_hit([0, 0, 0, 1, 4, 8], (10, 0, 0), (-1, 0, 0), 0.0, 100.0)
+    testing.assert_allclose(_flatten(hit, rec), (1, 1, 0, 0, 1, 0, 0, 9, 1, 0.5, 4, 8, SPHERE))
+    testing.assert_allclose(oracle.sphere_uv((-1, 0, 0)), (0.0, 0.5), atol=1e-7)
+    miss, _ = oracle.sphere_hit([0, 0, 0, 1, 4, 8], (10, 0, 0), (0, 1, 0), 0.0, 100.0)
+    assert not miss
+    inside, rec = oracle.sphere_hit([0, 0, 0, 1, 4, 8], (0, 0, 0), (0, 0, 1), 0.001, 100.0)
+    assert inside and rec[6] == 1.0  # the far root when the near one is behind t_min
+
+
+def test_rectangle_hit(oracle):
+    """rectangle_test.py:35-66 (exact 13-vector)."""
+    hit, rec = oracle.rectangle_hit([-1, 1, -1, 1, 1, 4, 8], (0, 0, 0), (0, 0, 1), 0.0, 100.0)
+    testing.assert_allclose(_flatten(hit, rec), (1, 0, 0, 1, 0, 0, 1, 1, 0.5, 0.5, 4, 8, RECTANGLE))
+
+
+def test_world_hit(oracle):
+    """world_test.py:131-196, plus the closest-hit rule over two shapes."""
+    from reinfocus_amd.graphics import shape, world
+
+    w = world.Worlds([shape.sphere(shape.v3f(0, 0, 0), 1, shape.v2f(4, 8))]).device_data()
+    hit, rec = oracle.world_hit(w[0][0], w[1][0], (10, 0, 0), (-1, 0, 0), 0.0, 100.0)
+    testing.assert_allclose(_flatten(hit, rec), (1, 1, 0, 0, 1, 0, 0, 9, 1, 0.5, 4, 8, SPHERE))
+    w = world.Worlds([shape.rectangle(shape.v2f(-1, 1), shape.v2f(-1, 1), 1, shape.v2f(4, 8))]).device_data()
+    hit, rec = oracle.world_hit(w[0][0], w[1][0], (0, 0, 0), (0, 0, 1), 0.0, 100.0)
+    testing.assert_allclose(_flatten(hit, rec), (1, 0, 0, 1, 0, 0, 1, 1, 0.5, 0.5, 4, 8, RECTANGLE))
+    two = world.Worlds([shape.rectangle(shape.v2f(-1, 1), shape.v2f(-1, 1), 5, shape.v2f(4, 8)),
+                        shape.sphere(shape.v3f(0, 0, 2), 0.5, shape.v2f(2, 2))]).device_data()
+    hit, rec = oracle.world_hit(two[0][0], two[1][0], (0, 0, 0), (0, 0, 1), 0.0, 100.0)
+    assert hit and rec[11] == SPHERE and rec[6] == 1.5  # the nearer sphere wins
+
+
+def test_worlds_packing():
+    """world_test.py:27-102."""
+    from reinfocus_amd.graphics import shape, world
+
+    testee = world.Worlds(
+        [shape.sphere(shape.v3f(1, 2, 3), 4, shape.v2f(5, 6)),
+         shape.rectangle(shape.v2f(-1, 1), shape.v2f(-1, 1), 1, shape.v2f(4, 8))],
+        [shape.rectangle(shape.v2f(-0.5, 0.5), shape.v2f(-0.5, 0.5), 0.5, shape.v2f(8, 4))])
+    params, types, sizes = testee.device_data()
+    assert len(testee) == 2
+    testing.assert_allclose(sizes, [2, 1])
+    testing.assert_allclose(params, [[[1, 2, 3, 4, 5, 6, 0], [-1, 1, -1, 1, 1, 4, 8]],
+                                     [[-0.5, 0.5, -0.5, 0.5, 0.5, 8, 4], [0] * 7]])
+    testing.assert_allclose(types, [[SPHERE, RECTANGLE], [RECTANGLE, SPHERE]])
+
+
+# --- camera_test.py -------------------------------------------------------------------------------
+
+
+def test_make_gpu_camera_and_cameras():
+    """camera_test.py:22-56 (Cameras row) and :114-141 (make_gpu_camera elements)."""
+    from reinfocus_amd.graphics import camera
+
+    cam = camera.make_gpu_camera(aperture=2, look_at=(0, 0, -1), vfov=90)
+    flat = np.concatenate([np.asarray(cam[k], dtype=np.float64) for k in range(6)] + [[cam[6]]])
+    testing.assert_allclose(flat, [-10, -10, -10, 20, 0, 0, 0, 20, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 1], atol=1e-5)
+    row = camera.Cameras(camera.make_gpu_camera()).device_data()
+    assert row.shape == (1, 19) and row.dtype == np.float64
+    testing.assert_allclose(row[0], [-2.68, -2.68, -10, 5.36, 0, 0, 0, 5.36, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0.05],
+                            atol=0.01)
+    assert row[0, 18] == 0.05
+
+
+# --- shape_factory_test.py -------------------------------------------------------------------------
+
+
+def test_shape_factory_types():
+    from reinfocus_amd.graphics import shape_factory as sf
+
+    def types(shapes):
+        return [s.shape_type for s in shapes]
+
+    assert types(sf.one_sphere()) == [SPHERE] and types(sf.two_sphere()) == [SPHERE] * 2
+    assert types(sf.one_rect()) == [RECTANGLE] and types(sf.two_rect()) == [RECTANGLE] * 2
+    assert set(types(sf.mixed())) == {SPHERE, RECTANGLE}
+    assert sf.get_absolute_size(sf.ShapeParameters(size=3.0)) == 3.0
+    assert abs(sf.get_absolute_size(sf.ShapeParameters(10.0, r_size=20)) - 1.7632698) < 1e-6
+
+
+# --- physics_test.py FindColourTest -------------------------------------------------------------------
+
+
+def test_find_colour(oracle):
+    """physics_test.py:175-246: a ray at a rectangle picks up red, at that sphere green."""
+    from reinfocus_amd.graphics import shape, world
+
+    w = world.Worlds([shape.rectangle(shape.v2f(-1, 1), shape.v2f(-1, 1), 1)]).device_data()
+    st = oracle.seed_states(1, 0)[0]
+    col = oracle.find_colour(w[0][0], w[1][0], (-(2**-4), -(2**-4), 0), (-(2**-4), -(2**-4), 1), st)
+    assert 0 < col[0] <= 1.0
+    testing.assert_allclose(col[1:3], [0, 0])
+    w = world.Worlds([shape.sphere(shape.v3f(0, 0, 10), 1)]).device_data()
+    st = oracle.seed_states(1, 0)[0]
+    col = oracle.find_colour(w[0][0], w[1][0], (-(2**-7), -(2**-6), 0), (-(2**-7), -(2**-6), 1), st)
+    assert 0 < col[1] <= 1.0
+    testing.assert_allclose(col[::2], [0, 0])
+
+
+# --- golden frames and the kernel arithmetic --------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["general_small", "general_rect"])
+def test_oracle_general_golden(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, h, w, spp = len(g["sizes"]), int(g["h"]), int(g["w"]), int(g["spp"])
+    st = oracle.seed_states(n * h * w, 0)
+    frames = oracle.render_general(g["cameras"], g["params"], g["types"], g["sizes"], h, w, spp, st, n_threads=4)
+    assert np.array_equal(frames, g["frames"]) and np.array_equal(st, g["states_after"])
+
+
+def _random_scene(rng, n):
+    from reinfocus_amd.graphics import camera, shape, world
+
+    cams, envs = [], []
+    for _ in range(n):
+        cams.append(camera.make_gpu_camera(aperture=rng.uniform(0.05, 0.4), focus_distance=rng.uniform(4, 12),
+                                           vfov=rng.uniform(25, 50), aspect_ratio=rng.uniform(0.8, 1.6),
+                                           look_from=(rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 0.0)))
+        shapes = []
+        for _ in range(rng.integers(1, 4)):
+            z = -rng.uniform(4, 12)
+            x, y = rng.uniform(-2, 2), rng.uniform(-1.5, 1.5)
+            tex = (int(rng.integers(1, 20)), int(rng.integers(1, 20)))
+            if rng.random() < 0.5:
+                shapes.append(shape.sphere(shape.v3f(x, y, z), rng.uniform(0.3, 1.5), shape.v2f(*tex)))
+            else:
+                s = rng.uniform(0.3, 2.0)
+                shapes.append(shape.rectangle(shape.v2f(x - s, x + s), shape.v2f(y - s, y + s), z, shape.v2f(*tex)))
+        envs.append(shapes)
+    return camera.Cameras(*cams).device_data(), world.Worlds(*envs).device_data()
+
+
+def test_general_kernel_arithmetic_equals_oracle(oracle):
+    """rf_general.h compiled for the host (tests/hostsim) on random multi-shape scenes."""
+    import subprocess
+
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
+    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    p = ctypes.c_void_p
+    hs.hs_render_general.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p]
+    rng = np.random.default_rng(17)
+    n, h, w, spp = 6, 14, 20, 4
+    cameras, (params, types, sizes) = _random_scene(rng, n)
+    if params.shape[2] < 7:
+        params = np.ascontiguousarray(np.pad(params, ((0, 0), (0, 0), (0, 7 - params.shape[2]))))
+    st0 = oracle.seed_states(n * h * w, 0)
+    st = st0.copy()
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=4)
+    got = np.zeros_like(want)
+    s2 = st0.copy()
+    cameras, types, sizes = (np.ascontiguousarray(a) for a in (cameras, types, sizes))
+    hs.hs_render_general(got.ctypes.data, n, h, w, spp, cameras.ctypes.data, params.ctypes.data, types.ctypes.data,
+                         sizes.ctypes.data, params.shape[1], params.shape[2], s2.ctypes.data)
+    assert np.array_equal(got, want) and np.array_equal(s2, st)
+    assert len(np.unique(want)) > 20  # the scenes really show something
+
+
+def test_render_average_colours(oracle):
+    """render_test.py:27-80: device_render of one_rect(r_size 30) and render() of
+    one_sphere(r_size 30) through make_gpu_camera(), 300 x 300, 100 spp."""
+    from reinfocus_amd.graphics import camera, shape_factory as sf, world
+
+    cams = camera.Cameras(camera.make_gpu_camera()).device_data()
+    p, t, s = world.Worlds(sf.one_rect(sf.ShapeParameters(r_size=30))).device_data()
+    st = oracle.seed_states(300 * 300, 0)
+    avg = np.average(oracle.render_general(cams, p, t, s, 300, 300, 100, st, n_threads=8), axis=(0, 1, 2))
+    assert np.all(avg >= np.multiply([0.25, 0.25, 0], 255)) and np.all(avg <= np.multiply([0.5, 0.5, 0], 255))
+    p, t, s = world.Worlds(sf.one_sphere(sf.ShapeParameters(r_size=30))).device_data()
+    p = np.ascontiguousarray(np.pad(p, ((0, 0), (0, 0), (0, 1))))
+    st = oracle.seed_states(300 * 300, 0)
+    avg = np.average(oracle.render_general(cams, p, t, s, 300, 300, 100, st, n_threads=8), axis=(0, 1, 2))
+    assert np.all(avg >= np.multiply([0.4, 0.4, 0.1], 255)) and np.all(avg <= np.multiply([0.6, 0.6, 0.2], 255))
