@@ -403,10 +403,11 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             b.rect = a.rect + (size_t)e0 * 2;
             b.n = ne;
             const dim3 grid(gx, ne), block(rf::kBlock);
+            const dim3 tiles(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH - 1) / rf::kTileH), ne);
             if (axis && ctx->coop && pow2)
-                hipLaunchKernelGGL((rf::render_kernel_coop<true>), grid, block, 0, ctx->stream, b);
+                hipLaunchKernelGGL((rf::render_kernel_coop<true>), tiles, block, 0, ctx->stream, b);
             else if (axis && ctx->coop)
-                hipLaunchKernelGGL((rf::render_kernel_coop<false>), grid, block, 0, ctx->stream, b);
+                hipLaunchKernelGGL((rf::render_kernel_coop<false>), tiles, block, 0, ctx->stream, b);
             else if (axis && pow2)
                 hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
             else if (axis)

@@ -178,6 +178,22 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
 #endif
 constexpr int kCoopTrips = RF_COOP_TRIPS;
 
+// Pixel <-> lane mapping of the cooperative kernel: a wave owns kWaveW x kWaveH pixels and a
+// block kWavesX x (4 / kWavesX) waves.  The mapping only changes which thread owns a pixel,
+// not the pixel's RNG stream, so it is a pure scheduling knob (a wave always reads / writes
+// whole 128-B lines of RNG state as long as kWaveW >= 8).  Measured at the headline config
+// (tools sweep, round 1): 32 x 2 pixel waves side by side (128 x 2 blocks) are 8 % faster
+// than 64 x 1 rows and than squarer tiles.
+#ifndef RF_WAVE_W
+#define RF_WAVE_W 32
+#endif
+#ifndef RF_WAVES_X
+#define RF_WAVES_X 4
+#endif
+constexpr int kWaveW = RF_WAVE_W, kWaveH = 64 / RF_WAVE_W;
+constexpr int kWavesX = RF_WAVES_X, kWavesY = (kBlock / 64) / RF_WAVES_X;
+constexpr int kTileW = kWavesX * kWaveW, kTileH = kWavesY * kWaveH;
+
 template <bool POW2>
 __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
 {
@@ -186,11 +202,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
 
     const int e = blockIdx.y;
     const int tid = threadIdx.x;
-    const int p = blockIdx.x * kBlock + tid; // pixel within the env
-    const bool live = p < a.hw;
-    const int y = live ? p / a.w : 0;
-    const int x = live ? p - y * a.w : 0;
-    const size_t pix = (size_t)e * a.hw + (live ? p : 0);
+    const int tiles_x = (a.w + kTileW - 1) / kTileW;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int col = (wv % kWavesX) * kWaveW + (lane % kWaveW); // column within the tile
+    const int row = (wv / kWavesX) * kWaveH + (lane / kWaveW); // row within the tile
+    const int x = tile_x * kTileW + col;
+    const int y = tile_y * kTileH + row;
+    const bool live = x < a.w && y < a.h;
+    const size_t pix = (size_t)e * a.hw + (live ? (size_t)y * a.w + x : 0);
 
     Rng g = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull); // dead lanes: any state
     if (live) {
@@ -244,21 +264,27 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     const uint8_t r8 = (uint8_t)(cr * a.scale);
     const uint8_t g8 = (uint8_t)(cg * a.scale);
     const uint8_t b8 = (uint8_t)(cb * a.scale);
-    const size_t block_px = (size_t)e * a.hw + (size_t)blockIdx.x * kBlock;
-    if ((a.hw & 3) == 0) {
+    if ((a.w & 3) == 0) {
+        // the tile's rows (kTileW * 3 B each) -> LDS -> coalesced dword stores per row
         uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
-        sb[tid * 3 + 0] = r8;
-        sb[tid * 3 + 1] = g8;
-        sb[tid * 3 + 2] = b8;
+        const int slot = row * kTileW + col;
+        sb[slot * 3 + 0] = r8;
+        sb[slot * 3 + 1] = g8;
+        sb[slot * 3 + 2] = b8;
         __syncthreads();
-        const int count = min(kBlock, a.hw - (int)blockIdx.x * kBlock);
-        const int ndw = count * 3 / 4;
-        if (tid < ndw) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(a.frames + block_px * 3);
-            dst[tid] = stage[tid];
+        constexpr int kRowDw = kTileW * 3 / 4; // dwords per tile row; kTileH * kRowDw == 192
+        if (tid < kTileH * kRowDw) {
+            const int r = tid / kRowDw, d = tid - r * kRowDw;
+            const int yy = tile_y * kTileH + r;
+            const int valid_dw = min(kTileW, a.w - tile_x * kTileW) * 3 / 4; // w % 4 == 0
+            if (yy < a.h && d < valid_dw) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(
+                    a.frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * kTileW) * 3);
+                dst[d] = stage[r * kRowDw + d];
+            }
         }
     } else if (live) {
-        uint8_t *dst = a.frames + (block_px + tid) * 3;
+        uint8_t *dst = a.frames + pix * 3;
         dst[0] = r8;
         dst[1] = g8;
         dst[2] = b8;
