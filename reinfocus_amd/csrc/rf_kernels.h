@@ -205,7 +205,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int wv = tid >> 6, lane = tid & 63;
-    const int col = (wv % kWavesX) * kWaveW + (lane % kWaveW); // column within the tile
+    // Tiles in the right half of the frame place their waves right to left, so that wave 0 --
+    // which finishes the cooperative tails -- is the outermost wave on both sides of the
+    // (centred) target: the one with the fewest hit lanes of its own (+2.6 % measured).
+    const bool mirror = (2 * tile_x + 1) * kTileW > a.w;
+    const int wx = mirror ? (kWavesX - 1 - wv % kWavesX) : (wv % kWavesX);
+    const int col = wx * kWaveW + (lane % kWaveW); // column within the tile
     const int row = (wv / kWavesX) * kWaveH + (lane / kWaveW); // row within the tile
     const int x = tile_x * kTileW + col;
     const int y = tile_y * kTileH + row;
