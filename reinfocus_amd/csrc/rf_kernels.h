@@ -110,41 +110,53 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
 // Block-cooperative tail of a rejection loop.  `need` marks the lanes whose loop has not
 // accepted yet after their in-wave attempts; on return every such lane holds the advanced
 // RNG state and the accepted raw draws in w[0 .. 2*DIM).  DIM = 2: disc, DIM = 3: sphere.
-// `parity` selects the s_cnt buffer (callers alternate it between consecutive calls).
+// `parity` selects the counter and the state buffer; callers alternate it between consecutive
+// calls.  Two barriers per call (one when nobody is left):
+//   park:    every wave takes slots with one LDS atomic (the order of the packed entries is
+//            irrelevant) and its stragglers write their RNG state            -- barrier --
+//   finish:  the first `total` threads of the block run the loops of the packed entries to
+//            the end and publish state + accepted draws                       -- barrier --
+//   collect: the owners read their entry back.
+// The state buffer is doubled because a fast wave parks the stragglers of the next call while
+// a slow one is still collecting; the draws are only written after the next call's first
+// barrier, and the counter of this parity is next touched two calls later.
 struct CoopLds {
-    uint4 state[kBlock];
+    uint4 state[2][kBlock];
     uint4 words4[kBlock];
     uint2 words2[kBlock];
-    int cnt[2][kBlock / 64];
+    int cnt[2];
 };
 
 template <int DIM>
 __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need, Rng &g, uint32_t *w)
 {
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    uint4 *const state = lds.state[parity];
     const unsigned long long ballot = __ballot(need);
-    if ((tid & 63) == 0)
-        lds.cnt[parity][wave] = __popcll(ballot);
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < kBlock / 64; ++i) {
-        const int c = lds.cnt[parity][i];
-        base += (i < wave) ? c : 0;
-        total += c;
+    int base = 0;
+    if (ballot != 0) { // wave-uniform
+        if ((tid & 63) == 0)
+            base = atomicAdd(&lds.cnt[parity], __popcll(ballot));
+        base = __builtin_amdgcn_readfirstlane(base);
     }
-    if (total == 0) // block-uniform
-        return;
     const int lane_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
     const int slot = base + lane_rank;
     if (need)
-        lds.state[slot] = make_uint4(g.a_lo, g.a_hi, g.b_lo, g.b_hi);
+        state[slot] = make_uint4(g.a_lo, g.a_hi, g.b_lo, g.b_hi);
     __syncthreads();
-    if (tid < total) { // packed stragglers: finish their loops on the first lanes of the block
-        const uint4 ps = lds.state[tid];
+    const int total = lds.cnt[parity];
+    if (total == 0) // block-uniform
+        return;
+    if (tid < total) {
+        const uint4 ps = state[tid];
         Rng wg{ps.x, ps.y, ps.z, ps.w};
         uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+#ifdef RF_WORKER_MAXTRIPS // timing experiment only: truncated tails, wrong frames
+        for (int trip = 0; trip < RF_WORKER_MAXTRIPS; ++trip)
+            if (DIM == 2 ? disc_attempt(wg, ww) : sphere_attempt(wg, ww))
+                break;
+#else
         if (DIM == 2) {
             while (!disc_attempt(wg, ww)) {
             }
@@ -152,14 +164,17 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
             while (!sphere_attempt(wg, ww)) {
             }
         }
-        lds.state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+#endif
+        state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
         lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
         if (DIM == 3)
             lds.words2[tid] = make_uint2(ww[4], ww[5]);
     }
     __syncthreads();
+    if (tid == 0)
+        lds.cnt[parity] = 0;
     if (need) {
-        const uint4 ps = lds.state[slot];
+        const uint4 ps = state[slot];
         g = Rng{ps.x, ps.y, ps.z, ps.w};
         const uint4 w4 = lds.words4[slot];
         w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
@@ -170,6 +185,9 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
     }
 }
 
+#ifndef RF_STAGE
+#define RF_STAGE 3
+#endif
 #ifndef RF_COOP_TRIPS
 #define RF_COOP_TRIPS 2
 #endif
@@ -202,6 +220,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
 
     const int e = blockIdx.y;
     const int tid = threadIdx.x;
+    if (tid < 2)
+        lds.cnt[tid] = 0;
+    __syncthreads();
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int wv = tid >> 6, lane = tid & 63;
@@ -229,6 +250,28 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     for (int k = 0; k < a.spp; ++k) {
         float s, t;
         sample_coords<POW2>(g, x, y, xf, yf, a.h, a.w, a.inv_w, a.inv_h, s, t);
+#if RF_STAGE == 0 // timing experiments only (tools/ab.sh): truncated sample pipelines
+        const Colour c{s, t, 0.0f};
+#elif RF_STAGE == 1
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+        bool dneed = live;
+        if (dneed && disc_attempt(g, w))
+            dneed = false;
+        coop_finish<2>(lds, 0, dneed, g, w);
+        float p0, p1;
+        disc_finish(w, p0, p1);
+        const Colour c{s + p0, t + p1, 0.0f};
+#elif RF_STAGE == 2
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+        bool dneed = live;
+        if (dneed && disc_attempt(g, w))
+            dneed = false;
+        coop_finish<2>(lds, 0, dneed, g, w);
+        float p0, p1;
+        disc_finish(w, p0, p1);
+        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s, t, a.tab);
+        const Colour c = sample_axis_shade(pre, p0, p1, s);
+#else
         uint32_t w[6] = {0, 0, 0, 0, 0, 0};
 #if RF_COOP_DISC
         bool dneed = live;
@@ -259,6 +302,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
         if (pre.hit)
             sphere_finish(w, q0, q1, q2);
         const Colour c = sample_axis_shade(pre, q0, q1, q2);
+#endif
         cr = add2(cr, c.r);
         cg = add2(cg, c.g);
         cb = add2(cb, c.b);

@@ -58,6 +58,10 @@ RF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s)
 #endif
 }
 
+#ifndef RF_SHL64
+#define RF_SHL64 1
+#endif
+
 // result = s0 + s1 (as two words), then the xoroshiro128+ 55/14/36 state update:
 // one v_lshl_add_u64 for the sum, v_alignbit_b32 funnel shifts for everything else
 // (13 VALU instructions; checked in the ISA).
@@ -73,7 +77,14 @@ RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
     // rotl(s0, 55) == rotr(s0, 9)
     const uint32_t ro_lo = funnel_r(a_hi, a_lo, 9), ro_hi = funnel_r(a_lo, a_hi, 9);
     // s1 << 14
+#if defined(__HIP_DEVICE_COMPILE__) && RF_SHL64
+    // one 64-bit shift issues in the time of one v_alignbit_b32 (tools/ubench)
+    uint64_t sh;
+    asm("v_lshlrev_b64 %0, 14, %1" : "=v"(sh) : "v"((((uint64_t)x_hi) << 32) | x_lo));
+    const uint32_t sh_lo = (uint32_t)sh, sh_hi = (uint32_t)(sh >> 32);
+#else
     const uint32_t sh_lo = x_lo << 14, sh_hi = funnel_r(x_hi, x_lo, 18);
+#endif
     g.a_lo = ro_lo ^ x_lo ^ sh_lo;
     g.a_hi = ro_hi ^ x_hi ^ sh_hi;
     // rotl(s1, 36) == rotl(swap halves, 4)
