@@ -19,6 +19,7 @@ Deliberate difference: the reference's RangedInitializer is unseeded
 
 import numpy as np
 
+from reinfocus_amd.environments import episode_visualizer
 from reinfocus_amd.environments import spaces
 from reinfocus_amd.environments import state_observer
 from reinfocus_amd.graphics import render
@@ -71,6 +72,15 @@ class _Ender:
         self._steps[indices] = 0
         self._diverging_steps[indices] = 0
         self._last_diff[indices] = abs(states[:, TARGET] - states[:, FOCUS])
+
+    def status(self, index):
+        """episode_ender.py:646-656, :191-207, :439-452: what the visualiser prints."""
+        diverging = self._diverging_steps[index]
+        r_status = f"diverging {diverging} / {self._early_end_steps}" if diverging > 0 else ""
+        if self._max_steps is None:
+            return r_status
+        l_status = f"step {self._steps[index]} / {self._max_steps}"
+        return l_status + (", " if l_status and r_status else "") + r_status
 
 
 def normaliser_constants(ends, max_move, min_focus, max_focus):
@@ -178,6 +188,9 @@ class VectorDiscreteSteps:
         # DiscreteMoveTransformer (state_transformer.py:222-266)
         self._action_set = np.concatenate([-moves, [0], moves[::-1]])
         self._limits = ends
+        # custom_environments.py:229-238; observation element 1 is the focus value
+        self._visualizer = episode_visualizer.HistoryVisualizer(
+            num_envs, TARGET, FOCUS, 1, self._renderer, ends, ender=self._ender, target_radius=target_radius)
 
         self.single_action_space = spaces.Discrete(len(self._action_set))
         self.action_space = spaces.batch_space(self.single_action_space, num_envs)
@@ -195,6 +208,8 @@ class VectorDiscreteSteps:
         self._ender.reset(self._state)
         observations = self._observer.reset(self._state, None)
         self._rewarder.reset(self._state, observations)
+        if self.render_mode == "rgb_array":
+            self._visualizer.reset(self._state, observations)
         return observations, {}
 
     def _transform(self, states, actions):
@@ -219,16 +234,25 @@ class VectorDiscreteSteps:
             new_observations = self._observer.reset(new_state, done)
             observations[done] = new_observations
             self._rewarder.reset(new_state, new_observations, done)
+            if self.render_mode == "rgb_array":
+                self._visualizer.reset(new_state, new_observations, done)
+        if self.render_mode == "rgb_array":
+            not_done = ~done
+            self._visualizer.step(self._state[not_done], observations[not_done], not_done)
         return observations, rewards, terminated, truncated, {}
 
     def render(self):
         """vector_environment.py:166-176 -> HistoryVisualizer.visualize
-        (episode_visualizer.py:188-197): only its renderer.render(600) call belongs to
-        the hot path (it advances / re-seeds the RNG states); the matplotlib compositing
-        is out of scope, the frames are returned as they are."""
+        (episode_visualizer.py:188-201): the 600 px rendering of every environment (which
+        advances / re-seeds the RNG states exactly as the reference's does) next to its
+        performance plot."""
         if self.render_mode == "rgb_array":
-            return np.asarray(self._renderer.render(600))
+            return self._visualizer.visualize()
         return None
+
+    def render_frames(self):
+        """Only the left halves of render(): uint8[num_envs, 600, 600, 3], no matplotlib."""
+        return np.asarray(self._renderer.render(600))
 
     def close(self):
         self._renderer._ctx.close()
@@ -252,6 +276,8 @@ class DiscreteSteps(VectorDiscreteSteps):
         self._state = self._transform(self._state, np.array([action]))
         self._ender.step(self._state)
         observations = self._observer.observe(self._state)
+        if self.render_mode == "rgb_array":  # environment.py:119-120
+            self._visualizer.step(self._state, observations)
         reward = self._rewarder.reward(self._state, observations)[0]
         return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
 
@@ -289,6 +315,8 @@ class ContinuousJumps(VectorDiscreteSteps):
         self._state = self._transform(self._state, np.array([action]))
         self._ender.step(self._state)
         observations = self._observer.observe(self._state)
+        if self.render_mode == "rgb_array":
+            self._visualizer.step(self._state, observations)
         stopped = (abs(self._state[:, FOCUS] - self._old_focus) < self._stop_threshold) * 1.0
         self._old_focus = self._state[:, FOCUS]
         on_target = (abs(self._state[:, TARGET] - self._state[:, FOCUS]) < 0.25) * 1.0 + 0.0

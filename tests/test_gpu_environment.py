@@ -23,8 +23,11 @@ def test_reference_notebook_outputs():
     assert obs.dtype == np.float32
     # the notebook shows numpy's 8-digit array repr: compare in that representation
     assert repr(obs) == "array([ 0.46703607, -0.84483975,  0.        ,  0.        ], dtype=float32)"
-    frames = env.render()
-    assert frames.shape == (1, 600, 600, 3)
+    image = env.render()  # HistoryVisualizer: 600 px rendering | 800 px wide plot
+    assert image.shape == (600, 1400, 3) and image.dtype == np.uint8
+    centre = image[250:350, 250:350]  # the (defocused) target: red / green checker, never blue
+    assert np.all(centre[..., 2] == 0) and np.all(centre[..., 0].astype(int) + centre[..., 1] > 0)
+    assert image[5, 5, 2] > 200  # sky in the corner
     obs, reward, terminated, truncated, _ = env.step(8)
     assert repr(obs) == "array([ 0.59203607, -0.873161  ,  0.0625    , -0.01416067], dtype=float32)"
     assert reward == -1.4981610774993896
@@ -139,3 +142,60 @@ def test_continuous_jumps_on_gpu():
     assert obs_on[1] > obs[1] or abs(env._state[0, 1] - target) < 1e-5
     assert reward_stay == np.float64(obs_stay[1]) + 1.0
     env.close()
+
+
+def test_vector_env_visualizer_follows_auto_resets():
+    """vector_environment.py:137-158 with render_mode="rgb_array": the visualiser is reset for
+    the done environments and stepped for the others; render() stacks one row per environment
+    and, through its 600 px render, advances the RNG states like the reference does."""
+    from reinfocus_amd.environments import harness
+
+    num_envs = 3
+    env = harness.VectorDiscreteSteps(max_episode_steps=2, num_envs=num_envs, render_mode="rgb_array",
+                                      frame_height=64, samples_per_pixel=4, seed=5, device=0)
+    twin = harness.VectorDiscreteSteps(max_episode_steps=2, num_envs=num_envs, frame_height=64,
+                                       samples_per_pixel=4, seed=5, device=0)
+    env.reset()
+    twin.reset()
+    image = env.render()
+    assert image.shape == (num_envs * 600, 1400, 3)
+    twin._renderer.render(600)  # what render() costs the RNG streams
+    actions = np.array([6, 7, 5])
+    for step in range(2):
+        got = env.step(actions)
+        want = twin.step(actions)
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b)
+    assert got[3].all()  # time limit: every environment was reset in the second step
+    visualizer = env._visualizer
+    assert list(visualizer._current_moves) == [0, 0, 0]
+    assert np.array_equal(visualizer._targets, env._state[:, 0])
+    assert all(len(visualizer._move_histories.get_history(i)) == 1 for i in range(num_envs))
+    env.close()
+    twin.close()
+
+
+def test_sb3_wrapper_over_device_environment():
+    """vector_shim.SB3Wrapper over the device-resident environment: the stable-baselines3
+    protocol returns exactly what the gymnasium-style API returns."""
+    from reinfocus_amd.environments import harness, vector_shim
+
+    kwargs = dict(max_episode_steps=3, num_envs=6, frame_height=64, samples_per_pixel=4, seed=11, device=0)
+    wrapped = vector_shim.SB3Wrapper(harness.DeviceVectorDiscreteSteps(**kwargs), None)
+    plain = harness.DeviceVectorDiscreteSteps(**kwargs)
+    assert np.array_equal(wrapped.reset(), plain.reset()[0])
+    generator = np.random.default_rng(2)
+    ended = 0
+    for _ in range(5):
+        actions = generator.integers(0, 13, size=6)
+        obs, rewards, dones, infos = wrapped.step(actions)
+        want_obs, want_rewards, terminated, truncated, _ = plain.step(actions)
+        assert np.array_equal(obs, want_obs) and np.array_equal(rewards, want_rewards)
+        assert np.array_equal(dones, terminated | truncated)
+        for i in range(6):
+            assert ("terminal_observation" in infos[i]) == bool(dones[i])
+        ended += int(dones.sum())
+    assert ended >= 6  # the 3-step time limit fired for every environment
+    assert wrapped.get_images() == [None]
+    wrapped.close()
+    plain.close()
