@@ -235,7 +235,7 @@ def main(argv=None):
             pmc_bpp, pmc_file = pmc_bytes_per_pixel()
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "render_kernel_coop<POW2>",
+                "kernel": "render_kernel_coop2<POW2>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

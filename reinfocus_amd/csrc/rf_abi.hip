@@ -22,6 +22,7 @@
 #include "rf_env.h"
 #include "rf_jump.h"
 #include "rf_kernels.h"
+#include "rf_coop2.h"
 
 namespace {
 
@@ -73,6 +74,7 @@ struct rf_ctx {
     rf::CamStatic cs{};
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
+    bool two_sets = true; // two pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
 
     uint8_t *d_frames = nullptr;
@@ -214,6 +216,8 @@ int rf_create(int device, rf_ctx **out)
     ctx->tab = make_checker_table();
     if (const char *v = getenv("REINFOCUS_RENDER_COOP"))
         ctx->coop = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
+        ctx->two_sets = v[0] != '1';
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
 
@@ -404,7 +408,12 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             b.n = ne;
             const dim3 grid(gx, ne), block(rf::kBlock);
             const dim3 tiles(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH - 1) / rf::kTileH), ne);
-            if (axis && ctx->coop && pow2)
+            const dim3 tiles2(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH2 - 1) / rf::kTileH2), ne);
+            if (axis && ctx->coop && ctx->two_sets && pow2)
+                hipLaunchKernelGGL((rf::render_kernel_coop2<true>), tiles2, block, 0, ctx->stream, b);
+            else if (axis && ctx->coop && ctx->two_sets)
+                hipLaunchKernelGGL((rf::render_kernel_coop2<false>), tiles2, block, 0, ctx->stream, b);
+            else if (axis && ctx->coop && pow2)
                 hipLaunchKernelGGL((rf::render_kernel_coop<true>), tiles, block, 0, ctx->stream, b);
             else if (axis && ctx->coop)
                 hipLaunchKernelGGL((rf::render_kernel_coop<false>), tiles, block, 0, ctx->stream, b);
