@@ -74,7 +74,7 @@ struct rf_ctx {
     rf::CamStatic cs{};
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
-    bool two_sets = true; // two pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
+    bool two_sets = true; // several pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
 
     uint8_t *d_frames = nullptr;

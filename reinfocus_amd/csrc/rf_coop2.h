@@ -1,21 +1,30 @@
-// rf_coop2.h -- render_kernel_coop2<POW2>: render_kernel_coop with two pixels per thread.
+// rf_coop2.h -- render_kernel_coop2<POW2>: render_kernel_coop with kSets pixels per thread.
 //
 // Same arithmetic, same pixel <-> RNG-state mapping, same cooperative tails as render_kernel_coop
-// (rf_kernels.h).  A block still has four waves, but its tile is twice as high (128 x 4 pixels):
-// a thread owns pixel (x, y) and pixel (x, y + 2).  Between two barriers every wave now does the
-// in-wave work of two pixel sets, and one cooperative call finishes the stragglers of both, so
-// the time a wave spends waiting for a tail is paid once per two samples' worth of work.
+// (rf_kernels.h).  A block still has four waves, but its tile is kSets times as high
+// (128 x 2 kSets pixels): a thread owns the pixels (x, y + 2 j), j < kSets.  Between two barriers
+// every wave now does the in-wave work of kSets pixel sets, and one cooperative call finishes
+// the stragglers of all of them, so the time a wave spends waiting for a tail -- more than half
+// of all wave-cycles in the one-set kernel -- is paid once per kSets samples' worth of work.
 #pragma once
 
 #include "rf_kernels.h"
 
 namespace rf {
 
-constexpr int kSets = 2;
+// Measured at the headline config (G samples/s; 1 set = render_kernel_coop = 122): 2 sets 133,
+// 3 sets 138 (at 7 waves per SIMD; 137 at 6, 132 at 8 with heavy spilling), 4 sets 114.
+#ifndef RF_SETS
+#define RF_SETS 3
+#endif
+#ifndef RF_SETS_OCC
+#define RF_SETS_OCC 7
+#endif
+constexpr int kSets = RF_SETS;
 constexpr int kTileH2 = kTileH * kSets;
 
 // coop_finish for kSets pixel sets at once.  The packed list holds at most kBlock entries (the
-// LDS arrays of CoopLds); stragglers that would not fit -- more than half of all lanes still
+// LDS arrays of CoopLds); stragglers that would not fit -- more than a third of all lanes still
 // looking, which does not happen in practice -- finish their loop in their own wave instead.
 template <int DIM>
 __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
@@ -95,7 +104,7 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
 }
 
 template <bool POW2>
-__global__ __launch_bounds__(kBlock, 8) void render_kernel_coop2(RenderArgs a)
+__global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
     __shared__ uint32_t stage[kSets * kBlock * 3 / 4];
     __shared__ CoopLds lds;
