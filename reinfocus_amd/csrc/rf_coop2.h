@@ -13,7 +13,13 @@
 namespace rf {
 
 // Measured at the headline config (G samples/s; 1 set = render_kernel_coop = 122): 2 sets 133,
-// 3 sets 138 (at 7 waves per SIMD; 137 at 6, 132 at 8 with heavy spilling), 4 sets 114.
+// 3 sets 138 (at 7 waves per SIMD; 135 at 6, 132 at 8 with heavy spilling), 4 sets 114.
+// Register spills are not affordable here even when they are cheap in time: every spilled dword
+// of a wave is 256 B of scratch traffic, and the first 3-set build moved 2.5x the algorithmic
+// HBM bytes.  The kernel therefore (a) re-derives the per-thread geometry inside the sample loop
+// from an index the compiler cannot see through, (b) moves block-uniform values that were
+// computed with vector instructions into scalar registers, (c) keeps the colour accumulators of
+// two of the three sets in LDS: 72 VGPRs, no scratch, traffic = algorithmic.
 #ifndef RF_SETS
 #define RF_SETS 3
 #endif
@@ -21,6 +27,9 @@ namespace rf {
 #define RF_SETS_OCC 7
 #endif
 constexpr int kSets = RF_SETS;
+#ifndef RF_COLOUR_LDS
+#define RF_COLOUR_LDS 2 // with the geometry / uniform tricks below: 72 VGPRs, no spills, 20.5 KB LDS
+#endif
 constexpr int kTileH2 = kTileH * kSets;
 
 // coop_finish for kSets pixel sets at once.  The packed list holds at most kBlock entries (the
@@ -30,7 +39,8 @@ template <int DIM>
 __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
                                              uint32_t (&w)[kSets][6])
 {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
     uint4 *const state = lds.state[parity];
     unsigned long long ballot[kSets];
     int pop = 0;
@@ -106,8 +116,15 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
 template <bool POW2>
 __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
-    __shared__ uint32_t stage[kSets * kBlock * 3 / 4];
     __shared__ CoopLds lds;
+    // the frame staging buffer (kSets * 768 B) reuses the words4 array once the sample loop is over
+    static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock * 3, "stage does not fit");
+    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.words4);
+#if RF_COLOUR_LDS > 0
+    // colour accumulators of the first RF_COLOUR_LDS pixel sets live in LDS (one read-modify-write
+    // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
+    __shared__ float lds_colour[RF_COLOUR_LDS][3][kBlock];
+#endif
 
     const int e = blockIdx.y;
     const int tid = threadIdx.x;
@@ -116,38 +133,74 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     __syncthreads();
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const int wv = tid >> 6, lane = tid & 63;
     const bool mirror = (2 * tile_x + 1) * kTileW > a.w; // see render_kernel_coop
-    const int wx = mirror ? (kWavesX - 1 - wv % kWavesX) : (wv % kWavesX);
-    const int col = wx * kWaveW + (lane % kWaveW);
-    const int row0 = (wv / kWavesX) * kWaveH + (lane / kWaveW); // set j is kTileH rows further down
-    const int x = tile_x * kTileW + col;
-    const float xf = (float)x;
 
-    // set j covers the rows kTileH * j further down; everything per set that is cheap to
-    // recompute (y, pixel index, liveness) is recomputed to keep two pixel states in 64 VGPRs
-    const int y0 = tile_y * kTileH2 + row0;
-    const bool live_x = x < a.w;
-    auto y_of = [&](int j) { return y0 + j * kTileH; };
-    auto live_of = [&](int j) { return live_x && y_of(j) < a.h; };
-    auto pix_of = [&](int j) { return (size_t)e * a.hw + (live_of(j) ? (size_t)y_of(j) * a.w + x : 0); };
+    // Pixel geometry of a thread.  Set j covers the rows kTileH * j further down.  All of it is
+    // cheap to derive from the thread index, and the sample loop derives it afresh every
+    // iteration from an index the compiler cannot see through (Geometry::opaque): kept alive
+    // across the loop these loop invariants -- x, y, their float forms as packed-math pairs,
+    // liveness masks, LDS addresses -- are what the register allocator spills.
+    struct Geometry {
+        int col, row0, x, y0;
+        bool live_x;
+        int h;
+        static __device__ __forceinline__ int opaque(int v)
+        {
+            asm volatile("" : "+v"(v));
+            return v;
+        }
+        __device__ __forceinline__ int y_of(int j) const { return y0 + j * kTileH; }
+        __device__ __forceinline__ bool live_of(int j) const { return live_x && y_of(j) < h; }
+    };
+    auto geometry = [&](int t) {
+        const int wv = t >> 6, lane = t & 63;
+        const int wx = mirror ? (kWavesX - 1 - wv % kWavesX) : (wv % kWavesX);
+        Geometry r;
+        r.col = wx * kWaveW + (lane % kWaveW);
+        r.row0 = (wv / kWavesX) * kWaveH + (lane / kWaveW);
+        r.x = tile_x * kTileW + r.col;
+        r.y0 = tile_y * kTileH2 + r.row0;
+        r.live_x = r.x < a.w;
+        r.h = a.h;
+        return r;
+    };
+    auto pix_of = [&](const Geometry &q, int j) {
+        return (size_t)e * a.hw + (q.live_of(j) ? (size_t)q.y_of(j) * a.w + q.x : 0);
+    };
     Rng g[kSets];
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
+        const Geometry g0 = geometry(tid);
         g[j] = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull); // dead lanes: any state
-        if (live_of(j)) {
-            const ulonglong2 st = a.states[pix_of(j)];
+        if (g0.live_of(j)) {
+            const ulonglong2 st = a.states[pix_of(g0, j)];
             g[j] = rng_load(st.x, st.y);
         }
     }
-    const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
+    PixelEnv env0 = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
+    // block-uniform values computed with vector instructions: keep them in scalar registers
+    auto uniform = [](float v) { // (the builtin alone is folded away for values known to be uniform)
+        int bits = __builtin_bit_cast(int, v);
+        asm volatile("" : "+v"(bits));
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(bits));
+    };
+    env0.tt = uniform(env0.tt);
+    env0.den = uniform(env0.den);
+    env0.rden = uniform(env0.rden);
 
     float cr[kSets], cg[kSets], cb[kSets];
 #pragma unroll
-    for (int j = 0; j < kSets; ++j)
+    for (int j = 0; j < kSets; ++j) {
         cr[j] = cg[j] = cb[j] = 0.0f;
+#if RF_COLOUR_LDS > 0
+        if (j < RF_COLOUR_LDS)
+            lds_colour[j][0][tid] = lds_colour[j][1][tid] = lds_colour[j][2][tid] = 0.0f;
+#endif
+    }
 
     for (int k = 0; k < a.spp; ++k) {
+        const Geometry gk = geometry(Geometry::opaque(tid));
+        const PixelEnv &env = env0;
         uint32_t w[kSets][6];
         float s[kSets], t[kSets];
         bool need[kSets];
@@ -156,8 +209,9 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 w[j][i] = 0;
-            sample_coords<POW2>(g[j], x, y_of(j), xf, (float)y_of(j), a.h, a.w, a.inv_w, a.inv_h, s[j], t[j]);
-            need[j] = live_of(j);
+            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h, a.w, a.inv_w, a.inv_h,
+                                s[j], t[j]);
+            need[j] = gk.live_of(j);
             if (need[j] && disc_attempt(g[j], w[j]))
                 need[j] = false;
         }
@@ -169,7 +223,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             float p0, p1;
             disc_finish(w[j], p0, p1);
             pre[j] = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s[j], t[j], a.tab);
-            need[j] = live_of(j) && pre[j].hit;
+            need[j] = gk.live_of(j) && pre[j].hit;
             for (int trip = 0; trip < kCoopTrips; ++trip) {
                 if (__any(need[j])) { // wave-uniform
                     if (need[j] && sphere_attempt(g[j], w[j]))
@@ -185,27 +239,45 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             if (pre[j].hit)
                 sphere_finish(w[j], q0, q1, q2);
             const Colour c = sample_axis_shade(pre[j], q0, q1, q2);
+#if RF_COLOUR_LDS > 0
+            if (j < RF_COLOUR_LDS) {
+                lds_colour[j][0][tid] = add2(lds_colour[j][0][tid], c.r);
+                lds_colour[j][1][tid] = add2(lds_colour[j][1][tid], c.g);
+                lds_colour[j][2][tid] = add2(lds_colour[j][2][tid], c.b);
+                continue;
+            }
+#endif
             cr[j] = add2(cr[j], c.r);
             cg[j] = add2(cg[j], c.g);
             cb[j] = add2(cb[j], c.b);
         }
     }
+#if RF_COLOUR_LDS > 0
+#pragma unroll
+    for (int j = 0; j < RF_COLOUR_LDS && j < kSets; ++j) {
+        cr[j] = lds_colour[j][0][tid];
+        cg[j] = lds_colour[j][1][tid];
+        cb[j] = lds_colour[j][2][tid];
+    }
+#endif
+    __syncthreads(); // the cooperative arrays are dead from here on: words4 becomes the stage
 
     uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+    const Geometry ge = geometry(Geometry::opaque(tid));
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
-        if (live_of(j))
-            a.states[pix_of(j)] = make_ulonglong2(rng_s0(g[j]), rng_s1(g[j]));
+        if (ge.live_of(j))
+            a.states[pix_of(ge, j)] = make_ulonglong2(rng_s0(g[j]), rng_s1(g[j]));
         const uint8_t r8 = (uint8_t)(cr[j] * a.scale);
         const uint8_t g8 = (uint8_t)(cg[j] * a.scale);
         const uint8_t b8 = (uint8_t)(cb[j] * a.scale);
         if ((a.w & 3) == 0) {
-            const int slot = (j * kTileH + row0) * kTileW + col;
+            const int slot = (j * kTileH + ge.row0) * kTileW + ge.col;
             sb[slot * 3 + 0] = r8;
             sb[slot * 3 + 1] = g8;
             sb[slot * 3 + 2] = b8;
-        } else if (live_of(j)) {
-            uint8_t *dst = a.frames + pix_of(j) * 3;
+        } else if (ge.live_of(j)) {
+            uint8_t *dst = a.frames + pix_of(ge, j) * 3;
             dst[0] = r8;
             dst[1] = g8;
             dst[2] = b8;
