@@ -91,7 +91,8 @@ class Ranks:
 def pmc_bytes_per_pixel():
     """HBM bytes per rendered pixel of the render kernel from the committed rocprofv3 PMC
     passes (profiles/<tag>_pmc.json: FETCH_SIZE doubled for gfx950's wide-read under-count,
-    WRITE_SIZE as is, divided by SQ_WAVES * 64 pixels).  None if no profile is present."""
+    WRITE_SIZE as is, divided by SQ_WAVES * pixels per wave; partial tiles at the frame's edge count
+    as whole ones: 258 instead of 256 rows at the headline size).  None if no profile is present."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
@@ -100,7 +101,8 @@ def pmc_bytes_per_pixel():
     data = json.load(open(files[-1]))
     for name, e in data.items():
         if "render_kernel" in name and e.get("SQ_WAVES") and "hbm_read_bytes_corrected" in e:
-            return (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / (e["SQ_WAVES"] * 64.0), os.path.basename(files[-1])
+            pixels = e["SQ_WAVES"] * float(e.get("pixels_per_wave", 64))
+            return (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / pixels, os.path.basename(files[-1])
     return None, None
 
 

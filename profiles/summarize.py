@@ -41,6 +41,9 @@ def main(tag):
             e["hbm_read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+        # pixels a wave of the render kernels owns (render_kernel_coop2: 3 pixel sets per thread)
+        if "render_kernel" in k:
+            e["pixels_per_wave"] = 192 if "render_kernel_coop2" in k else 64
         if "SQ_INSTS_VALU" in e and e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
         if "SQ_THREAD_CYCLES_VALU" in e and e.get("SQ_ACTIVE_INST_VALU"):
