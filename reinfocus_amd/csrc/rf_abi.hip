@@ -394,6 +394,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     const bool pow2 = is_pow2(h) && is_pow2(w);
     a.inv_w = 1.0f / (float)w;
     a.inv_h = 1.0f / (float)h;
+    a.rw64 = 1.0 / (double)w;
+    a.rh64 = 1.0 / (double)h;
 
     const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
     {

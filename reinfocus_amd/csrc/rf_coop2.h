@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             for (int i = 0; i < 6; ++i)
                 w[j][i] = 0;
             sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h, a.w, a.inv_w, a.inv_h,
-                                s[j], t[j]);
+                                a.rw64, a.rh64, s[j], t[j]);
             need[j] = gk.live_of(j);
             if (need[j] && disc_attempt(g[j], w[j]))
                 need[j] = false;

@@ -37,6 +37,7 @@ struct RenderArgs {
     int hw;          // h*w
     float scale;     // float32(255.0 / spp)   (render.py:244-246)
     float inv_w, inv_h; // exact reciprocals when w / h are powers of two
+    double rw64, rh64;  // RN64(1 / w), RN64(1 / h) for pixel_coord_div
 };
 
 // AXIS / POW2: exact specialisations, see rf_math.h render_pixel.
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
         const ulonglong2 st = a.states[pix];
         Rng g = rng_load(st.x, st.y);
         const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
-        render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, env, a.cs, a.tab, cr, cg, cb);
+        render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, a.rw64, a.rh64, env, a.cs, a.tab, cr, cg, cb);
         a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
     }
 
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     for (int k = 0; k < a.spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, a.h, a.w, a.inv_w, a.inv_h, s, t);
+        sample_coords<POW2>(g, x, y, xf, yf, a.h, a.w, a.inv_w, a.inv_h, a.rw64, a.rh64, s, t);
 #if RF_STAGE == 0 // timing experiments only (tools/ab.sh): truncated sample pipelines
         const Colour c{s, t, 0.0f};
 #elif RF_STAGE == 1

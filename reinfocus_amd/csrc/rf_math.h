@@ -452,6 +452,19 @@ RF_HD float pixel_coord_literal(int x, float xi, int w)
     return (float)(((double)x + (double)xi) / (double)w);
 }
 
+// The same value without the IEEE division expansion (~14 f64 instructions with v_rcp_f64):
+// w is a frame size, rw = RN64(1 / w) comes from the host.  q0 = RN(a * rw) is a faithful
+// quotient, the residual a - q0 * w is exact in one fma, and q = RN(q0 + rem * rw) is the
+// correctly rounded a / w (Markstein).  Checked against '/' for every frame size up to 4096
+// and > 10^9 numerators by tests/test_hostsim.py.
+RF_HD float pixel_coord_div(int x, float xi, double w, double rw)
+{
+    const double a = (double)x + (double)xi;
+    const double q0 = a * rw;
+    const double rem = __builtin_fma(-q0, w, a);
+    return (float)__builtin_fma(rem, rw, q0);
+}
+
 // For w a power of two the same value needs no f64: the f64 sum is either exact or
 // the addend is < 2^-28 ulp-wise irrelevant, so RN32(RN64(x+xi)) ==
 // RN32(x+xi) == the f32 add, and the division is an exact scaling.
@@ -594,26 +607,26 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s,
 // jittered pixel coordinates of one sample (render.py:229-234), two draws
 template <bool POW2>
 RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, int h, int w, float inv_w, float inv_h,
-                         float &s, float &t)
+                         double rw64, double rh64, float &s, float &t)
 {
     uint32_t xh, xl, yh, yl;
     rng_next(g, xh, xl);
     rng_next(g, yh, yl);
     const float xi = unit_f32_scaled48(xh, xl), yi = unit_f32_scaled48(yh, yl); // 2^48 * uniform
-    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_literal(x, xi * kTwoM48, w);
-    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_literal(y, yi * kTwoM48, h);
+    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM48, (double)w, rw64);
+    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM48, (double)h, rh64);
 }
 
 template <bool AXIS, bool POW2>
-RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w, float inv_h,
-                        const PixelEnv &e, const CamStatic &cs, const CheckerTable &tab, float &cr,
+RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w, float inv_h, double rw64,
+                        double rh64, const PixelEnv &e, const CamStatic &cs, const CheckerTable &tab, float &cr,
                         float &cg, float &cb)
 {
     cr = cg = cb = 0.0f;
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, h, w, inv_w, inv_h, s, t);
+        sample_coords<POW2>(g, x, y, xf, yf, h, w, inv_w, inv_h, rw64, rh64, s, t);
         Colour c = AXIS ? sample_axis(g, e, cs.lens_radius, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);
         cr = add2(cr, c.r);

@@ -35,6 +35,7 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
     const CamStatic cs{origin[0], origin[1], origin[2], u[0], u[1], u[2], v[0], v[1], v[2], lens_radius};
     const float scale = (float)(255.0 / (double)spp);
     const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+    const double rw64 = 1.0 / (double)w, rh64 = 1.0 / (double)h;
     for (int e = 0; e < n; ++e) {
         const PixelEnv env = make_pixel_env(cam_dyn + 9 * e, rect + 2 * e);
         for (int y = 0; y < h; ++y)
@@ -43,10 +44,10 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
                 Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
                 float cr, cg, cb;
                 switch (mode & 3) {
-                case 3: render_pixel<true, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
-                case 1: render_pixel<true, false>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
-                case 2: render_pixel<false, true>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
-                default: render_pixel<false, false>(g, x, y, h, w, spp, inv_w, inv_h, env, cs, tab, cr, cg, cb); break;
+                case 3: render_pixel<true, true>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
+                case 1: render_pixel<true, false>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
+                case 2: render_pixel<false, true>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
+                default: render_pixel<false, false>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
                 }
                 states[2 * pix] = rng_s0(g);
                 states[2 * pix + 1] = rng_s1(g);
@@ -103,6 +104,23 @@ long hs_check_pixel_coord(const float *xis, long n, int w)
         for (long i = 0; i < n; ++i)
             if (!(pixel_coord_pow2(x, xis[i], inv_w) == pixel_coord_literal(x, xis[i], w)))
                 ++bad;
+    return bad;
+}
+
+// pixel_coord_div vs pixel_coord_literal: every frame size w in [w_lo, w_hi], every x in [0, w)
+// (strided for large w unless every_x, so that each size costs about the same), all the given xis
+long hs_check_pixel_coord_div(const float *xis, long n, int w_lo, int w_hi, int every_x)
+{
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic)
+    for (int w = w_lo; w <= w_hi; ++w) {
+        const double rw = 1.0 / (double)w;
+        const int step = (w > 64 && !every_x) ? w / 64 : 1;
+        for (int x = 0; x < w; x += (x + step < w || x == w - 1) ? step : (w - 1 - x))
+            for (long i = 0; i < n; ++i)
+                if (!(pixel_coord_div(x, xis[i], (double)w, rw) == pixel_coord_literal(x, xis[i], w)))
+                    ++bad;
+    }
     return bad;
 }
 

@@ -28,6 +28,8 @@ def hs():
     lib.hs_check_uniform.argtypes = [p, ctypes.c_long]
     lib.hs_check_pixel_coord.restype = ctypes.c_long
     lib.hs_check_pixel_coord.argtypes = [p, ctypes.c_long, ctypes.c_int]
+    lib.hs_check_pixel_coord_div.restype = ctypes.c_long
+    lib.hs_check_pixel_coord_div.argtypes = [p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.hs_check_checker.restype = ctypes.c_long
     lib.hs_check_checker.argtypes = [p, p, ctypes.c_long]
     lib.hs_render.argtypes = [p] + [ctypes.c_int] * 4 + [p] * 5 + [ctypes.c_double, p, ctypes.c_int]
@@ -87,6 +89,24 @@ def test_pixel_coord_pow2_equals_literal(hs):
     ])
     for w in (1, 2, 64, 128, 256, 512, 1024, 4096):
         assert hs.hs_check_pixel_coord(xis.ctypes.data, len(xis), w) == 0
+
+
+def test_pixel_coord_division_free_form(hs):
+    """s = float32((x + xi) / w) for frame sizes that are not powers of two: the 3-op Markstein
+    quotient with the host's RN64(1 / w) equals the IEEE division for every w in [1, 4096]
+    (x strided to ~64 columns per size, 4100 jitters each: 1.1e9 quotients) and for every x of
+    the reference's own sizes 300 and 600."""
+    rng = np.random.default_rng(17)
+    xis = np.concatenate([
+        rng.random(2000, dtype=np.float32),
+        np.array([0, 1, 2.0**-53, 2.0**-30, 2.0**-24, 2.0**-25, 1 - 2.0**-24, 0.5, 2.0**-41, 2.0**-42, 2.0**-29],
+                 dtype=np.float32),
+        (rng.random(2089) * 2.0 ** -rng.integers(0, 50, 2089)).astype(np.float32),
+    ])
+    assert hs.hs_check_pixel_coord_div(xis.ctypes.data, len(xis), 1, 4096, 0) == 0
+    dense = rng.random(100_000, dtype=np.float32)
+    for w in (300, 600, 100, 720, 1080):
+        assert hs.hs_check_pixel_coord_div(dense.ctypes.data, len(dense), w, w, 1) == 0
 
 
 def test_checker_sign_equals_libm_sin(hs):
