@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreinfocus_hip.so")
+# REINFOCUS_HIP_LIB: an alternative build of the same library (tests use it for a build with a
+# tiny cooperative list); never a different implementation -- there is no CPU fallback
+LIB_PATH = os.environ.get("REINFOCUS_HIP_LIB") or os.path.join(_HERE, "libreinfocus_hip.so")
 
 RF_OK = 0
 RF_ERR_INVALID = -1

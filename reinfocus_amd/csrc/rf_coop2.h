@@ -27,6 +27,11 @@ namespace rf {
 #define RF_SETS_OCC 7
 #endif
 constexpr int kSets = RF_SETS;
+#ifndef RF_COOP_CAP
+#define RF_COOP_CAP kBlock // entries of the packed list; tests build a small one to force the overflow path
+#endif
+constexpr int kCoopCap = RF_COOP_CAP;
+static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in CoopLds");
 #ifndef RF_COLOUR_LDS
 #define RF_COLOUR_LDS 2 // with the geometry / uniform tricks below: 72 VGPRs, no spills, 20.5 KB LDS
 #endif
@@ -62,7 +67,7 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
         slot[j] = base + __builtin_amdgcn_mbcnt_hi((unsigned)(ballot[j] >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ballot[j], 0));
         base += (int)__popcll(ballot[j]);
-        parked[j] = need[j] && slot[j] < kBlock;
+        parked[j] = need[j] && slot[j] < kCoopCap;
         if (parked[j])
             state[slot[j]] = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
         if (need[j] && !parked[j]) { // overflow of the packed list: finish in place
@@ -76,7 +81,7 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
         }
     }
     __syncthreads();
-    const int total = min(lds.cnt[parity], kBlock);
+    const int total = min(lds.cnt[parity], kCoopCap);
     if (total == 0) // block-uniform
         return;
     if (tid < total) {

@@ -314,3 +314,42 @@ def test_fast_sqrt_and_reciprocal_are_ieee_exact(native):
     assert out[2] > 1_600_000_000          # values visited
     assert out[0] == 0, f"{out[0]} sqrt mismatches"
     assert out[1] == 0, f"{out[1]} reciprocal mismatches"
+
+
+def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path):
+    """render_kernel_coop2 packs the stragglers of a block into a 256-entry list and lets the
+    ones that do not fit finish in their own wave.  With the production capacity that path is
+    practically never taken, so tests/gpucheck builds the same library with a 32-entry list
+    (every all-hit block overflows) and a child process renders with it: frames and RNG states
+    must equal the oracle's, i.e. the production build's."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "gpucheck", "libreinfocus_cap32.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck"), "libreinfocus_cap32.so"])
+    n, h, spp = 3, 96, 8
+    d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
+    np.savez(tmp_path / "scene.npz", dyn=d[0], rect=d[1], origin=d[2], u=d[3], v=d[4], lens=d[5])
+    out = tmp_path / "cap32.npz"
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from reinfocus_amd import _native\n"
+        "d = np.load(%r)\n"
+        "c = _native.Context(0); c.seed(%d, 0, 0)\n"
+        "c.set_scene(d['dyn'], d['rect'], d['origin'], d['u'], d['v'], float(d['lens']))\n"
+        "f = c.render(%d, %d, %d, %d, to_host=True); s = c.get_states()\n"
+        "np.savez(%r, frames=f, states=s); c.close()\n"
+    ) % (os.path.dirname(here), str(tmp_path / "scene.npz"), n * h * h, n, h, h, spp, str(out))
+    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_HIP_LIB=so))
+    got = np.load(out)
+
+    states = oracle.seed_states(n * h * h, 0)
+    want = oracle.render(d[0], d[1], h, h, spp, states)
+    assert np.array_equal(got["frames"], want)
+    assert np.array_equal(got["states"], states)
+    # and the production build agrees, of course
+    ctx.seed(n * h * h, 0, 0)
+    ctx.set_scene(*d)
+    assert np.array_equal(ctx.render(n, h, h, spp, to_host=True), want)
