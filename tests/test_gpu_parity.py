@@ -316,23 +316,16 @@ def test_fast_sqrt_and_reciprocal_are_ieee_exact(native):
     assert out[1] == 0, f"{out[1]} reciprocal mismatches"
 
 
-def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path):
-    """render_kernel_coop2 packs the stragglers of a block into a 256-entry list and lets the
-    ones that do not fit finish in their own wave.  With the production capacity that path is
-    practically never taken, so tests/gpucheck builds the same library with a 32-entry list
-    (every all-hit block overflows) and a child process renders with it: frames and RNG states
-    must equal the oracle's, i.e. the production build's."""
+def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
+    """Renders `scene` in a child process whose environment selects another kernel / build of
+    the library (the selection is read once, at rf_create); returns frames and final states."""
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    so = os.path.join(here, "gpucheck", "libreinfocus_cap32.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck"), "libreinfocus_cap32.so"])
-    n, h, spp = 3, 96, 8
-    d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
-    np.savez(tmp_path / "scene.npz", dyn=d[0], rect=d[1], origin=d[2], u=d[3], v=d[4], lens=d[5])
-    out = tmp_path / "cap32.npz"
+    np.savez(tmp_path / "scene.npz", dyn=scene[0], rect=scene[1], origin=scene[2], u=scene[3], v=scene[4],
+             lens=scene[5])
+    out = tmp_path / "child.npz"
     script = (
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "from reinfocus_amd import _native\n"
@@ -342,14 +335,47 @@ def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path):
         "f = c.render(%d, %d, %d, %d, to_host=True); s = c.get_states()\n"
         "np.savez(%r, frames=f, states=s); c.close()\n"
     ) % (os.path.dirname(here), str(tmp_path / "scene.npz"), n * h * h, n, h, h, spp, str(out))
-    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_HIP_LIB=so))
+    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, **env_overrides))
     got = np.load(out)
+    return got["frames"], got["states"]
 
+
+@pytest.mark.parametrize("h", [96, 100])
+def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path, h):
+    """render_kernel_coop2 packs the stragglers of a block into a 256-entry list and lets the
+    ones that do not fit finish in their own wave.  With the production capacity that path is
+    practically never taken, so tests/gpucheck builds the same library with a 32-entry list
+    (every all-hit block overflows) and a child process renders with it: frames and RNG states
+    must equal the oracle's, i.e. the production build's."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "gpucheck", "libreinfocus_cap32.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck"), "libreinfocus_cap32.so"])
+    n, spp = 3, 8
+    d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
+    frames, final = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_HIP_LIB": so})
     states = oracle.seed_states(n * h * h, 0)
     want = oracle.render(d[0], d[1], h, h, spp, states)
-    assert np.array_equal(got["frames"], want)
-    assert np.array_equal(got["states"], states)
+    assert np.array_equal(frames, want)
+    assert np.array_equal(final, states)
     # and the production build agrees, of course
     ctx.seed(n * h * h, 0, 0)
     ctx.set_scene(*d)
     assert np.array_equal(ctx.render(n, h, h, spp, to_host=True), want)
+
+
+@pytest.mark.parametrize("overrides", [{"REINFOCUS_RENDER_SETS": "1"}, {"REINFOCUS_RENDER_COOP": "0"}],
+                         ids=["one-pixel-coop", "no-coop"])
+@pytest.mark.parametrize("h", [64, 50])
+def test_fallback_render_kernels_match_oracle(oracle, tmp_path, overrides, h):
+    """The kernels behind the switches (render_kernel_coop, render_kernel<AXIS, *>) stay
+    bit-identical to the oracle: power-of-two and other frame sizes."""
+    n, spp = 4, 5
+    rng = np.random.default_rng(12)
+    d = helpers.pack_scene(*helpers.random_scene(rng, n))
+    frames, final = _render_in_child(tmp_path, d, n, h, spp, overrides)
+    states = oracle.seed_states(n * h * h, 0)
+    assert np.array_equal(frames, oracle.render(d[0], d[1], h, h, spp, states))
+    assert np.array_equal(final, states)
