@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -156,6 +158,36 @@ struct Timed {
 };
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Splits the lens radius for rf_math.h lens_offset and decides -- by trying every float32 a disc
+// coordinate can be (multiples of 2^-24 in [-1, 0), of 2^-23 in [0, 1]) -- whether the float32
+// form reproduces float32(float64(p) * radius) for this radius.  ~60 ms on one core; remembered
+// per radius for the life of the process (the reference's FastCameras always uses 0.05).
+void lens_split(rf::CamStatic &cs)
+{
+    static std::mutex guard;
+    static std::map<double, bool> known;
+    const double radius = cs.lens_radius;
+    cs.lens_hi = (float)radius;
+    cs.lens_lo = (float)(radius - (double)cs.lens_hi);
+    cs.lens_f32 = 0;
+    if (!(radius == radius) || radius - radius != 0.0) // NaN / infinity: literal path
+        return;
+    std::lock_guard<std::mutex> lock(guard);
+    auto it = known.find(radius);
+    if (it == known.end()) {
+        bool exact = true;
+        const float hi = cs.lens_hi, lo = cs.lens_lo;
+        for (int k = 0; exact && k <= (1 << 24); ++k) {
+            const float neg = (float)((double)k * (1.0 / 16777216.0) - 1.0); // k 2^-24 - 1, exact
+            const float pos = (float)((double)k * (1.0 / 8388608.0));          // k 2^-23 (k <= 2^23)
+            exact = fmaf(neg, hi, neg * lo) == (float)((double)neg * radius) &&
+                    (k > (1 << 23) || fmaf(pos, hi, pos * lo) == (float)((double)pos * radius));
+        }
+        it = known.emplace(radius, exact).first;
+    }
+    cs.lens_f32 = it->second ? 1 : 0;
+}
 
 int ensure_frames(rf_ctx *ctx, int n, int h, int w)
 {
@@ -355,7 +387,8 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
     RF_HIP(hipStreamSynchronize(ctx->stream)); // host buffers are free again on return
 
     ctx->cs = rf::CamStatic{origin[0], origin[1], origin[2], u[0], u[1], u[2],
-                            v[0],      v[1],      v[2],      lens_radius};
+                            v[0],      v[1],      v[2],      lens_radius, 0.0f, 0.0f, 0};
+    lens_split(ctx->cs);
     // canonical frame of FastCameras() (camera.py:100-130): enables the AXIS kernel
     bool axis = origin[0] == 0.0f && origin[1] == 0.0f && origin[2] == 0.0f && u[0] == 1.0f &&
                 u[1] == 0.0f && u[2] == 0.0f && v[0] == 0.0f && v[1] == 1.0f && v[2] == 0.0f;
@@ -396,6 +429,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     a.inv_h = 1.0f / (float)h;
     a.rw64 = 1.0 / (double)w;
     a.rh64 = 1.0 / (double)h;
+    a.w64 = (double)w;
+    a.h64 = (double)h;
 
     const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
     {
@@ -411,10 +446,14 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             const dim3 grid(gx, ne), block(rf::kBlock);
             const dim3 tiles(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH - 1) / rf::kTileH), ne);
             const dim3 tiles2(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH2 - 1) / rf::kTileH2), ne);
-            if (axis && ctx->coop && ctx->two_sets && pow2)
-                hipLaunchKernelGGL((rf::render_kernel_coop2<true>), tiles2, block, 0, ctx->stream, b);
+            if (axis && ctx->coop && ctx->two_sets && pow2 && a.cs.lens_f32)
+                hipLaunchKernelGGL((rf::render_kernel_coop2<true, 1>), tiles2, block, 0, ctx->stream, b);
+            else if (axis && ctx->coop && ctx->two_sets && pow2)
+                hipLaunchKernelGGL((rf::render_kernel_coop2<true, 0>), tiles2, block, 0, ctx->stream, b);
+            else if (axis && ctx->coop && ctx->two_sets && a.cs.lens_f32)
+                hipLaunchKernelGGL((rf::render_kernel_coop2<false, 1>), tiles2, block, 0, ctx->stream, b);
             else if (axis && ctx->coop && ctx->two_sets)
-                hipLaunchKernelGGL((rf::render_kernel_coop2<false>), tiles2, block, 0, ctx->stream, b);
+                hipLaunchKernelGGL((rf::render_kernel_coop2<false, 0>), tiles2, block, 0, ctx->stream, b);
             else if (axis && ctx->coop && pow2)
                 hipLaunchKernelGGL((rf::render_kernel_coop<true>), tiles, block, 0, ctx->stream, b);
             else if (axis && ctx->coop)
@@ -748,7 +787,9 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     }
     ctx->env_host = *cfg;
     ctx->cs = rf::CamStatic{cfg->look_from[0], cfg->look_from[1], cfg->look_from[2], cfg->cam_u[0], cfg->cam_u[1],
-                            cfg->cam_u[2],     cfg->cam_v[0],     cfg->cam_v[1],     cfg->cam_v[2], cfg->lens_radius};
+                            cfg->cam_u[2],     cfg->cam_v[0],     cfg->cam_v[1],     cfg->cam_v[2], cfg->lens_radius,
+                            0.0f,              0.0f,              0};
+    lens_split(ctx->cs);
     // canonical frame -> horizontal = (h2, +0, +0), vertical = (+0, v2, +0): the AXIS kernels apply
     ctx->env_axis = cfg->look_from[0] == 0.0f && cfg->look_from[1] == 0.0f && cfg->look_from[2] == 0.0f &&
                     cfg->cam_u[0] == 1.0f && cfg->cam_u[1] == 0.0f && cfg->cam_u[2] == 0.0f &&

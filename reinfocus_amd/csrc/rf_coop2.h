@@ -118,7 +118,7 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
     }
 }
 
-template <bool POW2>
+template <bool POW2, int LENS>
 __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
     __shared__ CoopLds lds;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 w[j][i] = 0;
-            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h, a.w, a.inv_w, a.inv_h,
+            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h64, a.w64, a.inv_w, a.inv_h,
                                 a.rw64, a.rh64, s[j], t[j]);
             need[j] = gk.live_of(j);
             if (need[j] && disc_attempt(g[j], w[j]))
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         for (int j = 0; j < kSets; ++j) {
             float p0, p1;
             disc_finish(w[j], p0, p1);
-            pre[j] = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s[j], t[j], a.tab);
+            pre[j] = sample_axis_ray<LENS>(p0, p1, env, a.cs, s[j], t[j], a.tab);
             need[j] = gk.live_of(j) && pre[j].hit;
             for (int trip = 0; trip < kCoopTrips; ++trip) {
                 if (__any(need[j])) { // wave-uniform

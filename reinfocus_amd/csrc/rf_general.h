@@ -161,7 +161,7 @@ RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, con
     CamDyn dyn{(float)cam[0], (float)cam[1], (float)cam[2], (float)cam[3], (float)cam[4],
                (float)cam[5], (float)cam[6], (float)cam[7], (float)cam[8]};
     CamStatic cs{(float)cam[9],  (float)cam[10], (float)cam[11], (float)cam[12], (float)cam[13],
-                 (float)cam[14], (float)cam[15], (float)cam[16], (float)cam[17], cam[18]};
+                 (float)cam[14], (float)cam[15], (float)cam[16], (float)cam[17], cam[18], 0.0f, 0.0f, 0};
     cr = cg = cb = 0.0f;
     for (int k = 0; k < spp; ++k) {
         const float s = pixel_coord_literal(x, rng_uniform(g), w);

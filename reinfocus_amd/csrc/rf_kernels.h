@@ -38,6 +38,7 @@ struct RenderArgs {
     float scale;     // float32(255.0 / spp)   (render.py:244-246)
     float inv_w, inv_h; // exact reciprocals when w / h are powers of two
     double rw64, rh64;  // RN64(1 / w), RN64(1 / h) for pixel_coord_div
+    double w64, h64;    // (double)w, (double)h: scalar operands, no per-lane conversions
 };
 
 // AXIS / POW2: exact specialisations, see rf_math.h render_pixel.
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     for (int k = 0; k < a.spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, a.h, a.w, a.inv_w, a.inv_h, a.rw64, a.rh64, s, t);
+        sample_coords<POW2>(g, x, y, xf, yf, a.h64, a.w64, a.inv_w, a.inv_h, a.rw64, a.rh64, s, t);
 #if RF_STAGE == 0 // timing experiments only (tools/ab.sh): truncated sample pipelines
         const Colour c{s, t, 0.0f};
 #elif RF_STAGE == 1
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
         coop_finish<2>(lds, 0, dneed, g, w);
         float p0, p1;
         disc_finish(w, p0, p1);
-        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s, t, a.tab);
+        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs, s, t, a.tab);
         const Colour c = sample_axis_shade(pre, p0, p1, s);
 #else
         uint32_t w[6] = {0, 0, 0, 0, 0, 0};
@@ -285,9 +286,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
         coop_finish<2>(lds, 0, dneed, g, w);
         float p0, p1;
         disc_finish(w, p0, p1);
-        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs.lens_radius, s, t, a.tab);
+        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs, s, t, a.tab);
 #else
-        const AxisPre pre = sample_axis_pre(g, env, a.cs.lens_radius, s, t, a.tab);
+        const AxisPre pre = sample_axis_pre(g, env, a.cs, s, t, a.tab);
 #endif
 
         bool need = live && pre.hit;

@@ -163,7 +163,29 @@ struct CamStatic { // camera.py:39-52 FastGpuCameras minus the per-env array
     float ux, uy, uz;
     float vx, vy, vz;
     double lens_radius; // numpy.float64
+    // lens_radius = lens_hi + lens_lo + (at most 2^-48 of it); lens_f32 != 0 when the host has
+    // checked that the float32 form of lens_offset is exact for this radius (see there)
+    float lens_hi, lens_lo;
+    int lens_f32;
 };
+
+// camera.py:343 with vector.py:190: offset = float32(float64(p) * lens_radius) for a disc
+// coordinate p.  p is RN32(2u - 1) for a float32 u in [0, 1]: a multiple of 2^-24 in [-1, 0) or
+// of 2^-23 in [0, 1] -- 25 165 825 values.  With lens_radius split into two float32 terms,
+// fma(p, hi, RN32(p * lo)) carries a relative error below 2^-47 before its single rounding, so
+// it equals the doubly rounded reference unless p * lens_radius lies within 2^-47 of a float32
+// rounding boundary; whether that happens for any of the possible p is a property of the radius
+// alone, and the host checks all of them once per radius (rf_abi.hip lens_split; none for the
+// reference's aperture 0.1).  Otherwise the literal float64 form is used.
+// LENS: 1 / 0 = the form is fixed at compile time (the caller has looked at cs.lens_f32),
+// -1 = decided at run time.
+template <int LENS = -1>
+RF_HD float lens_offset(float p, const CamStatic &cs)
+{
+    if (LENS == 1 || (LENS == -1 && cs.lens_f32))
+        return __builtin_fmaf(p, cs.lens_hi, p * cs.lens_lo);
+    return (float)((double)p * cs.lens_radius);
+}
 
 struct CamDyn { // camera.py:54-56 FCAM_DYNAMIC_*
     float llx, lly, llz;
@@ -533,11 +555,12 @@ struct AxisPre {
     float dx, dy, dz; // primary ray direction (the sky direction of a miss)
 };
 
-RF_HD AxisPre sample_axis_ray(float p0, float p1, const PixelEnv &e, double lens_radius, float s, float t,
+template <int LENS = -1>
+RF_HD AxisPre sample_axis_ray(float p0, float p1, const PixelEnv &e, const CamStatic &cs, float s, float t,
                               const CheckerTable &tab)
 {
-    float ox = (float)((double)p0 * lens_radius);
-    float oy = (float)((double)p1 * lens_radius);
+    float ox = lens_offset<LENS>(p0, cs);
+    float oy = lens_offset<LENS>(p1, cs);
     AxisPre r;
     r.dx = (e.dyn.llx + e.dyn.hx * s) - ox;
     r.dy = (e.dyn.lly + e.dyn.vy * t) - oy;
@@ -586,18 +609,18 @@ RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
     return c;
 }
 
-RF_HD AxisPre sample_axis_pre(Rng &g, const PixelEnv &e, double lens_radius, float s, float t,
+RF_HD AxisPre sample_axis_pre(Rng &g, const PixelEnv &e, const CamStatic &cs, float s, float t,
                               const CheckerTable &tab)
 {
     float p0, p1;
     disc_sample(g, p0, p1);
-    return sample_axis_ray(p0, p1, e, lens_radius, s, t, tab);
+    return sample_axis_ray(p0, p1, e, cs, s, t, tab);
 }
 
-RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s, float t,
+RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, const CamStatic &cs, float s, float t,
                          const CheckerTable &tab)
 {
-    const AxisPre r = sample_axis_pre(g, e, lens_radius, s, t, tab);
+    const AxisPre r = sample_axis_pre(g, e, cs, s, t, tab);
     float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
     if (r.hit)
         sphere_sample(g, q0, q1, q2);
@@ -606,15 +629,15 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, double lens_radius, float s,
 
 // jittered pixel coordinates of one sample (render.py:229-234), two draws
 template <bool POW2>
-RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, int h, int w, float inv_w, float inv_h,
+RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, double h64, double w64, float inv_w, float inv_h,
                          double rw64, double rh64, float &s, float &t)
 {
     uint32_t xh, xl, yh, yl;
     rng_next(g, xh, xl);
     rng_next(g, yh, yl);
     const float xi = unit_f32_scaled48(xh, xl), yi = unit_f32_scaled48(yh, yl); // 2^48 * uniform
-    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM48, (double)w, rw64);
-    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM48, (double)h, rh64);
+    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM48, w64, rw64);
+    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM48, h64, rh64);
 }
 
 template <bool AXIS, bool POW2>
@@ -626,8 +649,8 @@ RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, h, w, inv_w, inv_h, rw64, rh64, s, t);
-        Colour c = AXIS ? sample_axis(g, e, cs.lens_radius, s, t, tab)
+        sample_coords<POW2>(g, x, y, xf, yf, (double)h, (double)w, inv_w, inv_h, rw64, rh64, s, t);
+        Colour c = AXIS ? sample_axis(g, e, cs, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);
         cr = add2(cr, c.r);
         cg = add2(cg, c.g);

@@ -32,7 +32,10 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
               double lens_radius, uint64_t *states, int mode)
 {
     const CheckerTable tab = host_checker_table();
-    const CamStatic cs{origin[0], origin[1], origin[2], u[0], u[1], u[2], v[0], v[1], v[2], lens_radius};
+    CamStatic cs{origin[0], origin[1], origin[2], u[0], u[1], u[2], v[0], v[1], v[2], lens_radius, 0.0f, 0.0f, 0};
+    cs.lens_hi = (float)lens_radius;
+    cs.lens_lo = (float)(lens_radius - (double)cs.lens_hi);
+    cs.lens_f32 = (mode >> 2) & 1; // bit 2: the float32 lens offset (the caller has checked the radius)
     const float scale = (float)(255.0 / (double)spp);
     const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
     const double rw64 = 1.0 / (double)w, rh64 = 1.0 / (double)h;
@@ -120,6 +123,26 @@ long hs_check_pixel_coord_div(const float *xis, long n, int w_lo, int w_hi, int 
             for (long i = 0; i < n; ++i)
                 if (!(pixel_coord_div(x, xis[i], (double)w, rw) == pixel_coord_literal(x, xis[i], w)))
                     ++bad;
+    }
+    return bad;
+}
+
+// lens_offset's float32 form against the literal float64 form for every possible disc
+// coordinate (multiples of 2^-24 in [-1, 0), of 2^-23 in [0, 1]); returns the mismatches
+long hs_check_lens(double radius)
+{
+    CamStatic lit{0, 0, 0, 1, 0, 0, 0, 1, 0, radius, 0.0f, 0.0f, 0};
+    CamStatic f32 = lit;
+    f32.lens_hi = (float)radius;
+    f32.lens_lo = (float)(radius - (double)f32.lens_hi);
+    f32.lens_f32 = 1;
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long k = 0; k <= (1l << 24) + (1l << 23); ++k) {
+        const float p = k < (1l << 24) ? (float)((double)k / 16777216.0 - 1.0)
+                                       : (float)((double)(k - (1l << 24)) / 8388608.0);
+        if (!(lens_offset(p, f32) == lens_offset(p, lit)))
+            ++bad;
     }
     return bad;
 }

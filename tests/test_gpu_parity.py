@@ -136,6 +136,25 @@ def test_render_general_camera_matches_oracle(ctx, oracle, h, w):
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
+@pytest.mark.parametrize("lens", [0.6243510725689605, 0.46456785704581477, 0.07, 0.0625],
+                         ids=["inexact-1", "inexact-5", "exact", "power-of-two"])
+@pytest.mark.parametrize("h", [64, 60])
+def test_lens_radius_forms(ctx, oracle, lens, h):
+    """offset = float32(float64(p) * lens_radius) (camera.py:343): the canonical-frame kernels
+    use a float32 fma form when the host finds it exact for the radius (rf_abi.hip lens_split)
+    and the literal float64 form otherwise -- e.g. for the first two radii here, for which 1 / 5
+    of the 25 M possible disc coordinates round differently (tests/test_hostsim.py)."""
+    n, spp = 3, 6
+    d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
+    cs = oracle.cam_static(d[2], d[3], d[4], lens)
+    st = oracle.seed_states(n * h * h, 0)
+    want = oracle.render(d[0], d[1], h, h, spp, st, cs=cs)
+    ctx.seed(n * h * h, 0, 0)
+    ctx.set_scene(d[0], d[1], d[2], d[3], d[4], lens)
+    assert np.array_equal(ctx.render(n, h, h, spp, to_host=True), want)
+    assert np.array_equal(ctx.get_states(0, n * h * h), st)
+
+
 def test_render_extreme_geometry(ctx, oracle):
     """Targets far outside [5, 10]: tiny/huge rectangles, strong defocus, t-range misses."""
     targets = np.array([1.0, 40.0, 0.0005, 2.0e6, 10.0, 5.0], dtype=np.float32)

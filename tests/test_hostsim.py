@@ -30,6 +30,8 @@ def hs():
     lib.hs_check_pixel_coord.argtypes = [p, ctypes.c_long, ctypes.c_int]
     lib.hs_check_pixel_coord_div.restype = ctypes.c_long
     lib.hs_check_pixel_coord_div.argtypes = [p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.hs_check_lens.restype = ctypes.c_long
+    lib.hs_check_lens.argtypes = [ctypes.c_double]
     lib.hs_check_checker.restype = ctypes.c_long
     lib.hs_check_checker.argtypes = [p, p, ctypes.c_long]
     lib.hs_render.argtypes = [p] + [ctypes.c_int] * 4 + [p] * 5 + [ctypes.c_double, p, ctypes.c_int]
@@ -107,6 +109,18 @@ def test_pixel_coord_division_free_form(hs):
     dense = rng.random(100_000, dtype=np.float32)
     for w in (300, 600, 100, 720, 1080):
         assert hs.hs_check_pixel_coord_div(dense.ctypes.data, len(dense), w, w, 1) == 0
+
+
+def test_lens_offset_float32_form(hs):
+    """offset = float32(float64(p) * lens_radius): for the reference's aperture 0.1 (radius
+    numpy.divide(0.1, 2.0) = 0.05) the float32 fma form is exact for all 25 165 825 possible disc
+    coordinates; radii for which it is not exist, and the C ABI then keeps the float64 form (the
+    same exhaustive check runs in rf_abi.hip lens_split)."""
+    assert hs.hs_check_lens(float(np.divide(0.1, 2.0))) == 0
+    assert hs.hs_check_lens(0.0625) == 0  # a power of two scales exactly
+    # about one radius in twelve has a few coordinates that round differently, e.g.:
+    assert hs.hs_check_lens(0.6243510725689605) == 1
+    assert hs.hs_check_lens(0.46456785704581477) == 5
 
 
 def test_checker_sign_equals_libm_sin(hs):
