@@ -27,6 +27,21 @@ namespace rf {
 #define RF_SETS_OCC 7
 #endif
 constexpr int kSets = RF_SETS;
+// Two packing rounds when the list needs more than one wave (measured, G samples/s: one round
+// 140.7; one attempt per entry in round 1: 142.9; two: 141.7; three / two: 139.0; round 2 only
+// above 128 entries: 140.0).
+#ifndef RF_TWO_ROUNDS
+#define RF_TWO_ROUNDS 1
+#endif
+#ifndef RF_TWO_ROUNDS_MIN
+#define RF_TWO_ROUNDS_MIN 64
+#endif
+#ifndef RF_R1_SPHERE
+#define RF_R1_SPHERE 1
+#endif
+#ifndef RF_R1_DISC
+#define RF_R1_DISC 1
+#endif
 #ifndef RF_COOP_CAP
 #define RF_COOP_CAP kBlock // entries of the packed list; tests build a small one to force the overflow path
 #endif
@@ -84,23 +99,90 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
     const int total = min(lds.cnt[parity], kCoopCap);
     if (total == 0) // block-uniform
         return;
-    if (tid < total) {
-        const uint4 ps = state[tid];
-        Rng wg{ps.x, ps.y, ps.z, ps.w};
-        uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-        if (DIM == 2) {
-            while (!disc_attempt(wg, ww)) {
+#if RF_TWO_ROUNDS
+    if (total > RF_TWO_ROUNDS_MIN) { // block-uniform
+        // Round 1: the packed entries make a bounded number of attempts on as many waves as they
+        // fill; the survivors are packed again -- into the other parity's state buffer, idle
+        // during this call -- and finished in round 2 by (usually) a single wave, instead of every
+        // worker wave dragging its own sparse tail.
+        uint4 *const other = lds.state[parity ^ 1];
+        if (tid < ((total + 63) & ~63)) { // whole waves
+            bool pend = tid < total;
+            Rng wg{0, 0, 0, 0};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (pend) {
+                const uint4 ps = state[tid];
+                wg = Rng{ps.x, ps.y, ps.z, ps.w};
+                for (int trip = 0; trip < (DIM == 2 ? RF_R1_DISC : RF_R1_SPHERE); ++trip) {
+                    if (DIM == 2 ? disc_attempt(wg, ww) : sphere_attempt(wg, ww)) {
+                        pend = false;
+                        break;
+                    }
+                }
+                if (!pend) {
+                    state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                    lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+                    if (DIM == 3)
+                        lds.words2[tid] = make_uint2(ww[4], ww[5]);
+                }
             }
-        } else {
-            while (!sphere_attempt(wg, ww)) {
+            const unsigned long long b2 = __ballot(pend);
+            if (b2 != 0) {
+                int base2 = 0;
+                if ((tid & 63) == 0)
+                    base2 = atomicAdd(&lds.cnt2, (int)__popcll(b2));
+                base2 = __builtin_amdgcn_readfirstlane(base2);
+                const int slot2 = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+                if (pend) {
+                    other[slot2] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                    lds.owner[slot2] = (uint16_t)tid;
+                }
             }
         }
-        state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-        lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-        if (DIM == 3)
-            lds.words2[tid] = make_uint2(ww[4], ww[5]);
+        __syncthreads();
+        const int total2 = lds.cnt2;
+        if (tid < total2) {
+            const uint4 ps = other[tid];
+            const int own = lds.owner[tid];
+            Rng wg{ps.x, ps.y, ps.z, ps.w};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (DIM == 2) {
+                while (!disc_attempt(wg, ww)) {
+                }
+            } else {
+                while (!sphere_attempt(wg, ww)) {
+                }
+            }
+            state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+            lds.words4[own] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+            if (DIM == 3)
+                lds.words2[own] = make_uint2(ww[4], ww[5]);
+        }
+        __syncthreads();
+        if (tid == 0)
+            lds.cnt2 = 0;
+    } else
+#endif
+    {
+        if (tid < total) {
+            const uint4 ps = state[tid];
+            Rng wg{ps.x, ps.y, ps.z, ps.w};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (DIM == 2) {
+                while (!disc_attempt(wg, ww)) {
+                }
+            } else {
+                while (!sphere_attempt(wg, ww)) {
+                }
+            }
+            state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+            lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+            if (DIM == 3)
+                lds.words2[tid] = make_uint2(ww[4], ww[5]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid == 0)
         lds.cnt[parity] = 0;
 #pragma unroll
@@ -135,6 +217,8 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     const int tid = threadIdx.x;
     if (tid < 2)
         lds.cnt[tid] = 0;
+    if (tid == 2)
+        lds.cnt2 = 0;
     __syncthreads();
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;

@@ -126,7 +126,9 @@ struct CoopLds {
     uint4 state[2][kBlock];
     uint4 words4[kBlock];
     uint2 words2[kBlock];
+    uint16_t owner[kBlock]; // render_kernel_coop2: original slot of a re-packed entry
     int cnt[2];
+    int cnt2;               // render_kernel_coop2: entries in the second round
 };
 
 template <int DIM>
