@@ -27,9 +27,14 @@ namespace rf {
 #define RF_SETS_OCC 7
 #endif
 constexpr int kSets = RF_SETS;
-// Two packing rounds when the list needs more than one wave (measured, G samples/s: one round
-// 140.7; one attempt per entry in round 1: 142.9; two: 141.7; three / two: 139.0; round 2 only
-// above 128 entries: 140.0).
+// Two packing rounds when the list needs more than one wave (measured, G samples/s, with two
+// in-wave sphere attempts: one round 140.7; one attempt per entry in round 1: 142.9; two: 141.7;
+// round 2 only above 128 entries: 140.0).  With the first packing round in place, the second
+// in-wave sphere attempt (48 % of the lanes) is better made there: one in-wave attempt and two
+// in round 1: 146.6 (three: 144.0) -- although an all-hit block then has ~366 stragglers for the
+// 256 entries of the list and the rest finish in place, which costs 10 % at 300 px where whole
+// tiles lie inside the target.  Hence the per-block switch in the kernel: 146.3 and, at 300 px /
+// 100 spp, 121.6 (always one attempt: 107.7, always two: 119.5).
 #ifndef RF_TWO_ROUNDS
 #define RF_TWO_ROUNDS 1
 #endif
@@ -37,8 +42,18 @@ constexpr int kSets = RF_SETS;
 #define RF_TWO_ROUNDS_MIN 64
 #endif
 #ifndef RF_R1_SPHERE
-#define RF_R1_SPHERE 1
+#define RF_R1_SPHERE 2
 #endif
+#ifndef RF_ADAPT_ON // hysteresis of the per-block switch between one and two in-wave sphere attempts
+#define RF_ADAPT_ON 32
+#endif
+#ifndef RF_ADAPT_OFF
+#define RF_ADAPT_OFF -32
+#endif
+#ifndef RF_COOP2_TRIPS
+#define RF_COOP2_TRIPS 1
+#endif
+constexpr int kCoopTrips2 = RF_COOP2_TRIPS; // in-wave sphere attempts before the cooperative call
 #ifndef RF_R1_DISC
 #define RF_R1_DISC 1
 #endif
@@ -55,9 +70,10 @@ constexpr int kTileH2 = kTileH * kSets;
 // coop_finish for kSets pixel sets at once.  The packed list holds at most kBlock entries (the
 // LDS arrays of CoopLds); stragglers that would not fit -- more than a third of all lanes still
 // looking, which does not happen in practice -- finish their loop in their own wave instead.
+// Returns the number of stragglers the block had (block-uniform).
 template <int DIM>
-__device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
-                                             uint32_t (&w)[kSets][6])
+__device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
+                                            uint32_t (&w)[kSets][6])
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
@@ -96,9 +112,10 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
         }
     }
     __syncthreads();
-    const int total = min(lds.cnt[parity], kCoopCap);
+    const int stragglers = lds.cnt[parity];
+    const int total = min(stragglers, kCoopCap);
     if (total == 0) // block-uniform
-        return;
+        return 0;
 #if RF_TWO_ROUNDS
     if (total > RF_TWO_ROUNDS_MIN) { // block-uniform
         // Round 1: the packed entries make a bounded number of attempts on as many waves as they
@@ -198,6 +215,7 @@ __device__ __forceinline__ void coop_finish2(CoopLds &lds, int parity, bool (&ne
             }
         }
     }
+    return stragglers;
 }
 
 template <bool POW2, int LENS>
@@ -287,6 +305,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 #endif
     }
 
+    int sphere_trips = kCoopTrips2; // in-wave sphere attempts of the current sample (block-uniform)
     for (int k = 0; k < a.spp; ++k) {
         const Geometry gk = geometry(Geometry::opaque(tid));
         const PixelEnv &env = env0;
@@ -313,14 +332,24 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             disc_finish(w[j], p0, p1);
             pre[j] = sample_axis_ray<LENS>(p0, p1, env, a.cs, s[j], t[j], a.tab);
             need[j] = gk.live_of(j) && pre[j].hit;
-            for (int trip = 0; trip < kCoopTrips; ++trip) {
-                if (__any(need[j])) { // wave-uniform
+#pragma unroll
+            for (int trip = 0; trip < kCoopTrips2 + 1; ++trip) {
+                if ((trip < kCoopTrips2 || sphere_trips > kCoopTrips2) && __any(need[j])) { // wave-uniform
                     if (need[j] && sphere_attempt(g[j], w[j]))
                         need[j] = false;
                 }
             }
         }
-        coop_finish2<3>(lds, 1, need, g, w);
+        // One in-wave attempt leaves ~48 % of a hit wave's lanes for the packed list, which is where
+        // a second attempt is best made (full waves) -- unless the list then overflows: a block
+        // whose tile lies inside the target has ~366 such lanes for 256 entries, and the rest would
+        // finish in place.  So a block switches to two in-wave attempts when its list overflowed
+        // on the previous sample, and back when it would fit again with one.
+        const int stragglers = coop_finish2<3>(lds, 1, need, g, w);
+        if (sphere_trips == kCoopTrips2 && stragglers > kCoopCap + RF_ADAPT_ON)
+            sphere_trips = kCoopTrips2 + 1;
+        else if (sphere_trips != kCoopTrips2 && 2 * stragglers < kCoopCap + RF_ADAPT_OFF)
+            sphere_trips = kCoopTrips2;
 
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
