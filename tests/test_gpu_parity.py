@@ -94,6 +94,10 @@ def test_render_golden(native, golden_dir, name):
         (2, 128, 32, 5),     # h != w, both powers of two
         (1, 300, 300, 1),    # reference default frame height
         (256, 16, 16, 2),    # many small envs
+        (3, 1, 1, 7),        # a single pixel
+        (2, 7, 130, 3),      # just over one tile wide, one partial tile row
+        (2, 6, 128, 2),      # exactly one tile per env
+        (1, 13, 129, 2),     # partial tiles in both directions
     ],
 )
 def test_render_matches_oracle(ctx, oracle, n, h, w, spp):
