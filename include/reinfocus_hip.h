@@ -72,7 +72,8 @@ int rf_set_states(rf_ctx *ctx, uint64_t first, uint64_t count, const uint64_t *h
 
 /* Uploads the scene of `n` environments.
  *   cam_dyn  float32[n][3][3]  rows: lower_left, horizontal, vertical
- *   rect     float32[n][2]     (half_side, z_pos)
+ *   rect     float32[n][2]     (half_side, z_pos); a half_side with the bit pattern 0x7FC0DEAD (a
+ *                              NaN no arithmetic produces) marks a slot that render and focus skip
  *   origin, u, v  float32[3]   shared camera frame;  lens_radius float64
  * Replaces: the two cuda.to_device uploads in FastCameras._make_device_data
  * (graphics/camera.py:144-179) and FastWorlds._make_device_data

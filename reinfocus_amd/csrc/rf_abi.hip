@@ -526,7 +526,7 @@ int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in)
 namespace {
 
 // enqueues the focus measure of the first n frames into ctx->d_var (device)
-int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
+int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr)
 {
     // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
     const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
@@ -558,6 +558,7 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode)
             a.h = h;
             a.w = w;
             a.gray15 = gray_mode == RF_GRAY_15BIT;
+            a.skip_rect = skip_rect ? skip_rect + (size_t)e0 * 2 : nullptr;
             if (quad)
                 hipLaunchKernelGGL(rf::focus_kernel_quad, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
             else
@@ -851,21 +852,42 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const float *)ctx->d_pool);
     RF_HIP(hipGetLastError());
-    // the step's flags and rewards are final here; the count sizes the partial render
     int k = 0;
-    RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipStreamSynchronize(ctx->stream));
-    if (k > 0) { // vector_environment.py:137-151: partial render of the envs that just ended
-        rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+    // vector_environment.py:137-151: partial render of the envs that just ended.  Small
+    // configurations are launch- and sync-bound: there the partial render is enqueued for all n
+    // slots right away (env_reset_kernel has marked the unused ones, whose blocks exit at once) and
+    // the step ends with its only host synchronisation.  Large ones size the partial launch by the
+    // count, which costs one round trip and saves up to a few hundred thousand empty blocks.
+    const long tiles = (long)((fh + rf::kTileW - 1) / rf::kTileW) * ((fh + rf::kTileH2 - 1) / rf::kTileH2);
+    const bool one_sync = (long)n * tiles <= 65536;
+    if (one_sync) {
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
         if (rc == RF_OK)
-            rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
         if (rc != RF_OK)
             return rc;
-        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((n + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
                            ctx->env, (const double *)ctx->d_var);
         RF_HIP(hipGetLastError());
+        RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        // the step's flags and rewards are final here; the count sizes the partial render
+        RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (k > 0) {
+            rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+            if (rc == RF_OK)
+                rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+            if (rc != RF_OK)
+                return rc;
+            hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
+                               ctx->env, (const double *)ctx->d_var);
+            RF_HIP(hipGetLastError());
+        }
     }
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 
     const int e = blockIdx.y;
     const int tid = threadIdx.x;
+    if (skip_env(a.rect, e)) // block-uniform, before any barrier
+        return;
     if (tid < 2)
         lds.cnt[tid] = 0;
     if (tid == 2)

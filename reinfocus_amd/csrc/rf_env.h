@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rf_math.h"
+
 namespace rf {
 
 struct EnvConfig {
@@ -186,6 +188,9 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
     }
     if (threadIdx.x == 0)
         *s.done_count = running;
+    // the auto-reset render is enqueued for all n slots: mark the ones it has to skip
+    for (int r = running + (int)threadIdx.x; r < c.n; r += 1024)
+        s.rect2[2 * r] = __builtin_bit_cast(float, kSkipEnvBits);
 }
 
 // observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the

@@ -26,6 +26,11 @@ namespace rf {
 
 constexpr int kBlock = 256;
 
+__device__ __forceinline__ bool skip_env(const float *rect, int e)
+{
+    return __builtin_bit_cast(uint32_t, rect[2 * (size_t)e]) == kSkipEnvBits;
+}
+
 struct RenderArgs {
     uint8_t *frames;
     ulonglong2 *states;
@@ -48,6 +53,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
     __shared__ uint32_t stage[kBlock * 3 / 4];
 
     const int e = blockIdx.y;
+    if (skip_env(a.rect, e)) // block-uniform, before any barrier
+        return;
     const int p = blockIdx.x * kBlock + threadIdx.x; // pixel within the env
     const bool live = p < a.hw;
 
@@ -223,6 +230,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     __shared__ CoopLds lds;
 
     const int e = blockIdx.y;
+    if (skip_env(a.rect, e)) // block-uniform, before any barrier
+        return;
     const int tid = threadIdx.x;
     if (tid < 2)
         lds.cnt[tid] = 0;
@@ -392,6 +401,7 @@ struct FocusArgs {
     unsigned long long *sums; // [n][2] = (sum, sum of squares), zeroed before launch
     int n, h, w;
     int gray15; // 1: 15-bit coefficients, 0: 14-bit
+    const float *skip_rect; // scene rectangles when slots may be marked kSkipEnvBits, else null
 };
 
 __device__ __forceinline__ uint32_t gray_of(uint32_t r, uint32_t g, uint32_t b, int gray15)
@@ -424,6 +434,8 @@ __global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int e = blockIdx.y;
+    if (a.skip_rect != nullptr && skip_env(a.skip_rect, e))
+        return;
     const int r0 = blockIdx.x * kBand;               // first output row
     const int r1 = min(r0 + kBand, a.h);             // one past last output row
     const int w = a.w, h = a.h;
@@ -530,6 +542,8 @@ __global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int e = blockIdx.y;
+    if (a.skip_rect != nullptr && skip_env(a.skip_rect, e))
+        return;
     const int w = a.w, h = a.h, wq = a.w >> 2;
     const int r0 = blockIdx.x * kBandQ, r1 = min(r0 + kBandQ, h);
     const int m0 = max(r0 - 1, 0), m1 = min(r1 + 1, h); // median rows needed

@@ -158,6 +158,11 @@ RF_HD float rng_uniform(Rng &g) { return rng_uniform48(g) * kTwoM48; } // exact 
 // ---------------------------------------------------------------------------
 // scene parameters
 // ---------------------------------------------------------------------------
+// rect[e].half of an environment slot that a launch has to skip: the device-resident env step
+// enqueues the auto-reset render for all n slots before it knows how many environments ended
+// (no host round trip in the middle of a step); env_reset_kernel marks the unused slots.
+constexpr uint32_t kSkipEnvBits = 0x7FC0DEADu; // a quiet NaN no arithmetic produces
+
 struct CamStatic { // camera.py:39-52 FastGpuCameras minus the per-env array
     float ox, oy, oz;
     float ux, uy, uz;
