@@ -47,6 +47,9 @@ def parse_args(argv=None):
                     help="device: whole step resident on the GPU (rf_env_*); host: numpy glue around "
                          "rf_render / rf_focus (identical results, tests/test_gpu_environment.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="no per-kernel HIP events (and no roofline object): lets small configurations replay "
+                         "their step as one hipGraph")
     ap.add_argument("--plumbing-test", action="store_true",
                     help="no GPU work: exercises only the multi-rank plumbing (CPU tests)")
     return ap.parse_args(argv)
@@ -182,7 +185,8 @@ def main(argv=None):
         one_step()
 
     if env is not None:
-        ctx.timing(True)
+        if not args.no_kernel_timing:
+            ctx.timing(True)
         ctx.synchronize()
     ranks.barrier()
     t0 = time.perf_counter()
@@ -196,7 +200,7 @@ def main(argv=None):
     elapsed = ranks.reduce(elapsed_local, "MAX")
     total_resets = ranks.reduce(resets, "SUM")
 
-    timing = ctx.timing_read() if env is not None else None
+    timing = ctx.timing_read() if env is not None and not args.no_kernel_timing else None
     total_envs = n_local * ranks.world
     value = total_envs * args.steps / elapsed if env is not None else None
 

@@ -97,6 +97,12 @@ struct rf_ctx {
     void *env_block = nullptr; // one allocation holding every EnvState array
     int *d_actions = nullptr;
     float *d_pool = nullptr;
+    // small configurations replay their (host-independent) step as one hipGraph
+    bool env_graph_enabled = true; // REINFOCUS_ENV_GRAPH=0 disables
+    hipGraphExec_t env_graph = nullptr;
+    uint8_t *h_stage = nullptr;    // pinned: actions | pool | obs | rewards | truncated | count
+    size_t h_stage_bytes = 0;
+    uint64_t env_steps = 0;
     bool env_axis = false;
 
     bool timing = false;
@@ -156,6 +162,16 @@ struct Timed {
         }
     }
 };
+
+// The captured env step (rf_env_step) holds device pointers and kernel arguments by value: any
+// call that may reallocate a buffer or change the scene / configuration drops it.
+void drop_env_graph(rf_ctx *ctx)
+{
+    if (ctx->env_graph)
+        (void)hipGraphExecDestroy(ctx->env_graph);
+    ctx->env_graph = nullptr;
+    ctx->env_steps = 0;
+}
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -250,6 +266,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->coop = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
         ctx->two_sets = v[0] != '1';
+    if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))
+        ctx->env_graph_enabled = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
 
@@ -296,6 +314,8 @@ int rf_destroy(rf_ctx *ctx)
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_var) (void)hipFree(ctx->d_var);
+    if (ctx->env_graph) (void)hipGraphExecDestroy(ctx->env_graph);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->env_block) (void)hipFree(ctx->env_block);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -309,6 +329,7 @@ int rf_seed(rf_ctx *ctx, uint64_t n_states, uint64_t seed, uint64_t first_state_
     RF_REQUIRE(first_state_index + n_states < (1ull << rf::kSeedMats),
                "rf_seed: state index exceeds 2^%d", rf::kSeedMats);
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     if (n_states != ctx->n_states) {
         RF_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->d_states)
@@ -357,6 +378,7 @@ int rf_set_states(rf_ctx *ctx, uint64_t first, uint64_t count, const uint64_t *h
     RF_REQUIRE(first + count <= ctx->n_states, "rf_set_states: range exceeds %llu states",
                (unsigned long long)ctx->n_states);
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     RF_HIP(hipMemcpyAsync(ctx->d_states + first, host_in, count * sizeof(ulonglong2),
                           hipMemcpyHostToDevice, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));
@@ -370,6 +392,7 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
     RF_REQUIRE(n > 0, "rf_set_scene: n must be positive");
     RF_REQUIRE(cam_dyn && rect && origin && u && v, "rf_set_scene: NULL argument");
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     if (n > ctx->scene_cap) {
         RF_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->d_cam) RF_HIP(hipFree(ctx->d_cam));
@@ -487,6 +510,7 @@ int rf_render(rf_ctx *ctx, int n, int h, int w, int spp, uint8_t *host_out)
     RF_REQUIRE(need <= ctx->n_states, "rf_render: %llu pixels but only %llu RNG states (rf_seed first)",
                (unsigned long long)need, (unsigned long long)ctx->n_states);
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     int rc = launch_render(ctx, n, h, w, spp, ctx->d_cam, ctx->d_rect, ctx->axis);
     if (rc != RF_OK)
         return rc;
@@ -514,6 +538,7 @@ int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in)
     RF_REQUIRE(ctx != nullptr && host_in != nullptr, "rf_upload_frames: NULL argument");
     RF_REQUIRE(n > 0 && h > 0 && w > 0, "rf_upload_frames: n, h, w must be positive");
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     RF_HIP(hipStreamSynchronize(ctx->stream));
     int rc = ensure_frames(ctx, n, h, w);
     if (rc != RF_OK)
@@ -581,6 +606,7 @@ int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var)
                ctx->fw);
     RF_REQUIRE(gray_mode == RF_GRAY_15BIT || gray_mode == RF_GRAY_14BIT, "rf_focus: gray_mode must be 14 or 15");
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     int rc = launch_focus(ctx, n, h, w, gray_mode);
     if (rc != RF_OK)
         return rc;
@@ -601,6 +627,7 @@ int rf_synchronize(rf_ctx *ctx)
 {
     RF_REQUIRE(ctx != nullptr, "rf_synchronize: ctx is NULL");
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     RF_HIP(hipStreamSynchronize(ctx->stream));
     return RF_OK;
 }
@@ -609,6 +636,7 @@ int rf_timing(rf_ctx *ctx, int enable)
 {
     RF_REQUIRE(ctx != nullptr, "rf_timing: ctx is NULL");
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     RF_HIP(hipStreamSynchronize(ctx->stream));
     double dummy_ms = 0.0;
     uint64_t dummy_n = 0;
@@ -643,6 +671,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                       const int32_t *types, const int32_t *sizes, int most, int width, uint8_t *host_out)
 {
     RF_REQUIRE(ctx != nullptr && cameras && params && types && sizes, "rf_render_general: NULL argument");
+    drop_env_graph(ctx);
     RF_REQUIRE(n > 0 && h > 0 && w > 0 && spp > 0 && most > 0 && width >= 7, "rf_render_general: bad sizes");
     RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render_general: frame too large");
     for (int e = 0; e < n; ++e) {
@@ -723,6 +752,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     RF_REQUIRE(need <= ctx->n_states, "rf_env_configure: %llu pixels but only %llu RNG states (rf_seed first)",
                (unsigned long long)need, (unsigned long long)ctx->n_states);
     RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
     RF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->env_block) {
         RF_HIP(hipFree(ctx->env_block));
@@ -825,6 +855,54 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     return RF_OK;
 }
 
+namespace {
+
+bool env_one_sync(const rf_ctx *ctx)
+{
+    const int n = ctx->env_host.n, fh = ctx->env_host.frame_height;
+    const long tiles = (long)((fh + rf::kTileW - 1) / rf::kTileW) * ((fh + rf::kTileH2 - 1) / rf::kTileH2);
+    return (long)n * tiles <= 65536;
+}
+
+// Enqueues one whole step on the ctx's stream without waiting for anything: uploads, the full
+// render + focus, the glue kernels, the auto-reset render for all n slots (env_reset_kernel marks
+// the unused ones, whose blocks exit at once), the downloads.  Used directly and under stream
+// capture.
+int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, float *obs, double *rewards,
+                     uint8_t *truncated, int *count)
+{
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    const dim3 grid((n + 255) / 256), block(256);
+    RF_HIP(hipMemcpyAsync(ctx->d_actions, actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipMemcpyAsync(ctx->d_pool, pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const int *)ctx->d_actions);
+    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+    if (rc != RF_OK)
+        return rc;
+    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const double *)ctx->d_var, 0);
+    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const float *)ctx->d_pool);
+    rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
+    if (rc != RF_OK)
+        return rc;
+    hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const double *)ctx->d_var);
+    RF_HIP(hipMemcpyAsync(count, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    return RF_OK;
+}
+
+} // namespace
+
 int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool, float *host_obs,
                 double *host_rewards, uint8_t *host_truncated, int *host_n_reset)
 {
@@ -837,42 +915,77 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     for (int i = 0; i < n; ++i)
         RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions, "rf_env_step: action %d of env %d out of range",
                    host_actions[i], i);
-    RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    const dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const int *)ctx->d_actions);
-    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
-    if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
-    if (rc != RF_OK)
-        return rc;
-    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)ctx->d_var, 0);
-    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const float *)ctx->d_pool);
-    RF_HIP(hipGetLastError());
     int k = 0;
-    // vector_environment.py:137-151: partial render of the envs that just ended.  Small
-    // configurations are launch- and sync-bound: there the partial render is enqueued for all n
-    // slots right away (env_reset_kernel has marked the unused ones, whose blocks exit at once) and
-    // the step ends with its only host synchronisation.  Large ones size the partial launch by the
-    // count, which costs one round trip and saves up to a few hundred thousand empty blocks.
-    const long tiles = (long)((fh + rf::kTileW - 1) / rf::kTileW) * ((fh + rf::kTileH2 - 1) / rf::kTileH2);
-    const bool one_sync = (long)n * tiles <= 65536;
-    if (one_sync) {
-        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+    // vector_environment.py:137-151: the envs that just ended are rendered again.  Small
+    // configurations are launch- and sync-bound: their step is enqueued in one go (see
+    // enqueue_env_step) and, from the second step on (all buffers have their final size by then),
+    // replayed as one hipGraph through pinned staging buffers; it ends with its only host
+    // synchronisation.  Large ones size the auto-reset launch by the count, which costs one round
+    // trip and saves up to a few hundred thousand empty blocks.
+    if (env_one_sync(ctx)) {
+        const size_t o_pool = (size_t)n * 4, o_obs = o_pool + (size_t)n * 8, o_rew = o_obs + (size_t)n * 16,
+                     o_tru = o_rew + (size_t)n * 8, o_cnt = (o_tru + (size_t)n + 7) & ~(size_t)7, bytes = o_cnt + 8;
+        const bool graph = ctx->env_graph_enabled && !ctx->timing && ctx->env_steps >= 1;
+        if (!graph) {
+            int rc = enqueue_env_step(ctx, host_actions, host_pool, host_obs, host_rewards, host_truncated, &k);
+            if (rc != RF_OK)
+                return rc;
+            RF_HIP(hipGetLastError());
+            RF_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (ctx->h_stage_bytes < bytes) {
+                if (ctx->env_graph)
+                    (void)hipGraphExecDestroy(ctx->env_graph);
+                ctx->env_graph = nullptr;
+                if (ctx->h_stage)
+                    RF_HIP(hipHostFree(ctx->h_stage));
+                ctx->h_stage = nullptr;
+                ctx->h_stage_bytes = 0;
+                RF_HIP(hipHostMalloc((void **)&ctx->h_stage, bytes, hipHostMallocDefault));
+                ctx->h_stage_bytes = bytes;
+            }
+            uint8_t *st = ctx->h_stage;
+            if (!ctx->env_graph) {
+                hipGraph_t captured = nullptr;
+                RF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
+                                          (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
+                const hipError_t end = hipStreamEndCapture(ctx->stream, &captured);
+                if (rc != RF_OK) {
+                    if (captured)
+                        (void)hipGraphDestroy(captured);
+                    return rc;
+                }
+                RF_HIP(end);
+                const hipError_t inst = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(captured);
+                RF_HIP(inst);
+            }
+            memcpy(st, host_actions, (size_t)n * 4);
+            memcpy(st + o_pool, host_pool, (size_t)n * 8);
+            RF_HIP(hipGraphLaunch(ctx->env_graph, ctx->stream));
+            RF_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(host_obs, st + o_obs, (size_t)n * 16);
+            memcpy(host_rewards, st + o_rew, (size_t)n * 8);
+            memcpy(host_truncated, st + o_tru, (size_t)n);
+            k = *(const int *)(st + o_cnt);
+        }
+    } else {
+        RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        const dim3 grid((n + 255) / 256), block(256);
+        hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const int *)ctx->d_actions);
+        int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
         if (rc == RF_OK)
-            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
         if (rc != RF_OK)
             return rc;
-        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((n + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
-                           ctx->env, (const double *)ctx->d_var);
+        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)ctx->d_var, 0);
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool);
         RF_HIP(hipGetLastError());
-        RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
         // the step's flags and rewards are final here; the count sizes the partial render
         RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -888,9 +1001,10 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                                ctx->env, (const double *)ctx->d_var);
             RF_HIP(hipGetLastError());
         }
+        RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_steps += 1;
     if (host_n_reset)
         *host_n_reset = k;
     return RF_OK;
