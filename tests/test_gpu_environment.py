@@ -127,6 +127,35 @@ def test_device_resident_step_equals_host_harness(n, height, spp, steps):
     dev.close()
 
 
+def test_env_step_graph_survives_other_calls_on_the_context():
+    """Small configurations replay rf_env_step as one hipGraph from their second step on.  The
+    graph holds device pointers and kernel arguments by value, so every call that may reallocate a
+    buffer or change the scene drops it; the steps around such calls must stay identical to the
+    numpy harness (which never sees them)."""
+    from reinfocus_amd import vision
+    from reinfocus_amd.environments import harness
+
+    kw = dict(num_envs=48, frame_height=32, samples_per_pixel=3, seed=4, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    assert np.array_equal(host.reset()[0], dev.reset()[0])
+    rng = np.random.default_rng(8)
+    foreign = rng.integers(0, 256, size=(3, 80, 64, 3), dtype=np.uint8)
+    for step in range(24):
+        if step % 7 == 3:  # someone scores foreign frames on the environment's own context
+            dev._ctx.upload_frames(foreign)
+            values = dev._ctx.focus(3, 80, 64, vision.GRAY_MODE)
+            assert values.shape == (3,) and np.all(values > 0)
+        actions = rng.integers(0, 13, 48)
+        want = host.step(actions)
+        got = dev.step(actions)
+        for a, b in zip(want[:4], got[:4]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(host._state, dev._state)
+    host.close()
+    dev.close()
+
+
 def test_continuous_jumps_on_gpu():
     from reinfocus_amd import registration
 
