@@ -857,6 +857,13 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
 
 namespace {
 
+bool env_one_sync(const rf_ctx *ctx)
+{
+    const int n = ctx->env_host.n, fh = ctx->env_host.frame_height;
+    const long tiles = (long)((fh + rf::kTileW - 1) / rf::kTileW) * ((fh + rf::kTileH2 - 1) / rf::kTileH2);
+    return (long)n * tiles <= 65536;
+}
+
 // Enqueues one whole step on the ctx's stream without waiting for anything: uploads, the full
 // render + focus, the glue kernels, the auto-reset render for all n slots (env_reset_kernel marks
 // the unused ones, whose blocks exit at once), the downloads.  Used directly and under stream
@@ -904,63 +911,98 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     RF_REQUIRE(ctx->env_ready, "rf_env_step: rf_env_configure first");
     RF_HIP(hipSetDevice(ctx->device));
     const rf_env_config &h = ctx->env_host;
-    const int n = h.n;
+    const int n = h.n, fh = h.frame_height;
     for (int i = 0; i < n; ++i)
         RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions, "rf_env_step: action %d of env %d out of range",
                    host_actions[i], i);
     int k = 0;
-    // vector_environment.py:137-151: the envs that just ended are rendered again.  The whole step
-    // is enqueued in one go (enqueue_env_step: no host round trip to size the auto-reset launch)
-    // and ends with its only host synchronisation; from the second step on -- all buffers have
-    // their final size by then -- it is replayed as one hipGraph through pinned staging buffers,
-    // which is what small, launch-bound configurations need (per-kernel timing events switch the
-    // replay off).
-    const size_t o_pool = (size_t)n * 4, o_obs = o_pool + (size_t)n * 8, o_rew = o_obs + (size_t)n * 16,
-                 o_tru = o_rew + (size_t)n * 8, o_cnt = (o_tru + (size_t)n + 7) & ~(size_t)7, bytes = o_cnt + 8;
-    const bool graph = ctx->env_graph_enabled && !ctx->timing && ctx->env_steps >= 1;
-    if (!graph) {
-        int rc = enqueue_env_step(ctx, host_actions, host_pool, host_obs, host_rewards, host_truncated, &k);
+    // vector_environment.py:137-151: the envs that just ended are rendered again.  Small
+    // configurations are launch- and sync-bound: their step is enqueued in one go (see
+    // enqueue_env_step) and, from the second step on (all buffers have their final size by then),
+    // replayed as one hipGraph through pinned staging buffers; it ends with its only host
+    // synchronisation.  Large ones size the auto-reset launch by the count, which costs one round
+    // trip and saves up to a few hundred thousand empty blocks.
+    if (env_one_sync(ctx)) {
+        const size_t o_pool = (size_t)n * 4, o_obs = o_pool + (size_t)n * 8, o_rew = o_obs + (size_t)n * 16,
+                     o_tru = o_rew + (size_t)n * 8, o_cnt = (o_tru + (size_t)n + 7) & ~(size_t)7, bytes = o_cnt + 8;
+        const bool graph = ctx->env_graph_enabled && !ctx->timing && ctx->env_steps >= 1;
+        if (!graph) {
+            int rc = enqueue_env_step(ctx, host_actions, host_pool, host_obs, host_rewards, host_truncated, &k);
+            if (rc != RF_OK)
+                return rc;
+            RF_HIP(hipGetLastError());
+            RF_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (ctx->h_stage_bytes < bytes) {
+                if (ctx->env_graph)
+                    (void)hipGraphExecDestroy(ctx->env_graph);
+                ctx->env_graph = nullptr;
+                if (ctx->h_stage)
+                    RF_HIP(hipHostFree(ctx->h_stage));
+                ctx->h_stage = nullptr;
+                ctx->h_stage_bytes = 0;
+                RF_HIP(hipHostMalloc((void **)&ctx->h_stage, bytes, hipHostMallocDefault));
+                ctx->h_stage_bytes = bytes;
+            }
+            uint8_t *st = ctx->h_stage;
+            if (!ctx->env_graph) {
+                hipGraph_t captured = nullptr;
+                RF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
+                                          (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
+                const hipError_t end = hipStreamEndCapture(ctx->stream, &captured);
+                if (rc != RF_OK) {
+                    if (captured)
+                        (void)hipGraphDestroy(captured);
+                    return rc;
+                }
+                RF_HIP(end);
+                const hipError_t inst = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(captured);
+                RF_HIP(inst);
+            }
+            memcpy(st, host_actions, (size_t)n * 4);
+            memcpy(st + o_pool, host_pool, (size_t)n * 8);
+            RF_HIP(hipGraphLaunch(ctx->env_graph, ctx->stream));
+            RF_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(host_obs, st + o_obs, (size_t)n * 16);
+            memcpy(host_rewards, st + o_rew, (size_t)n * 8);
+            memcpy(host_truncated, st + o_tru, (size_t)n);
+            k = *(const int *)(st + o_cnt);
+        }
+    } else {
+        RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        const dim3 grid((n + 255) / 256), block(256);
+        hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const int *)ctx->d_actions);
+        int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
         if (rc != RF_OK)
             return rc;
+        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)ctx->d_var, 0);
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool);
         RF_HIP(hipGetLastError());
+        // the step's flags and rewards are final here; the count sizes the partial render
+        RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         RF_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-        if (ctx->h_stage_bytes < bytes) {
-            if (ctx->env_graph)
-                (void)hipGraphExecDestroy(ctx->env_graph);
-            ctx->env_graph = nullptr;
-            if (ctx->h_stage)
-                RF_HIP(hipHostFree(ctx->h_stage));
-            ctx->h_stage = nullptr;
-            ctx->h_stage_bytes = 0;
-            RF_HIP(hipHostMalloc((void **)&ctx->h_stage, bytes, hipHostMallocDefault));
-            ctx->h_stage_bytes = bytes;
-        }
-        uint8_t *st = ctx->h_stage;
-        if (!ctx->env_graph) {
-            hipGraph_t captured = nullptr;
-            RF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
-                                      (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
-            const hipError_t end = hipStreamEndCapture(ctx->stream, &captured);
-            if (rc != RF_OK) {
-                if (captured)
-                    (void)hipGraphDestroy(captured);
+        if (k > 0) {
+            rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+            if (rc == RF_OK)
+                rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+            if (rc != RF_OK)
                 return rc;
-            }
-            RF_HIP(end);
-            const hipError_t inst = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(captured);
-            RF_HIP(inst);
+            hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
+                               ctx->env, (const double *)ctx->d_var);
+            RF_HIP(hipGetLastError());
         }
-        memcpy(st, host_actions, (size_t)n * 4);
-        memcpy(st + o_pool, host_pool, (size_t)n * 8);
-        RF_HIP(hipGraphLaunch(ctx->env_graph, ctx->stream));
+        RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
         RF_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(host_obs, st + o_obs, (size_t)n * 16);
-        memcpy(host_rewards, st + o_rew, (size_t)n * 8);
-        memcpy(host_truncated, st + o_tru, (size_t)n);
-        k = *(const int *)(st + o_cnt);
     }
     ctx->env_steps += 1;
     if (host_n_reset)
