@@ -1,76 +1,77 @@
-// rf_coop2.h -- render_kernel_coop2<POW2>: render_kernel_coop with kSets pixels per thread.
+// rf_coop2.h -- render_kernel_coop2<POW2, LENS>: the default render kernel.
 //
-// Same arithmetic, same pixel <-> RNG-state mapping, same cooperative tails as render_kernel_coop
-// (rf_kernels.h).  A block still has four waves, but its tile is kSets times as high
-// (128 x 2 kSets pixels): a thread owns the pixels (x, y + 2 j), j < kSets.  Between two barriers
-// every wave now does the in-wave work of kSets pixel sets, and one cooperative call finishes
-// the stragglers of all of them, so the time a wave spends waiting for a tail -- more than half
-// of all wave-cycles in the one-set kernel -- is paid once per kSets samples' worth of work.
+// Same arithmetic, same pixel <-> RNG-state mapping and the same idea as render_kernel_coop
+// (rf_kernels.h) -- lanes whose rejection loop is not done after their in-wave attempts hand their
+// RNG state to a packed list in LDS that full waves finish -- with three refinements, each
+// measured at the headline config (G samples/s; render_kernel_coop: 122):
+//
+//  * kSets = 3 pixels per thread (tile 128 x 6: a thread owns (x, y + 2 j), j < 3).  57 % of
+//    the one-pixel kernel's wave-cycles are barrier waits for the tails; now every wave does the
+//    in-wave work of three pixel sets between two barriers and one cooperative call serves all
+//    three.  2 / 3 / 4 sets: 133 / 138 / 114.  Spilling is not an option even where it is cheap in
+//    time (every spilled dword of a wave is 256 B of scratch traffic: the first 3-set build moved
+//    2.5x the algorithmic HBM bytes), so the kernel (a) re-derives the per-thread geometry inside
+//    the sample loop from an index the compiler cannot see through -- the loop invariants were
+//    what got spilled --, (b) moves block-uniform values computed with vector instructions into
+//    scalar registers, (c) keeps the colour accumulators of two sets in LDS and (d) stages the
+//    frame through a cooperative array: 72 VGPRs (7 waves per SIMD), no scratch, 20.5 KB LDS.
+//  * a packing round (RF_TWO_ROUNDS): when the list needs more than one wave, its entries first
+//    make a bounded number of attempts on as many waves as they fill and the survivors are packed
+//    again, so that a single wave runs the sparse end of the tail: +1.5 %.
+//  * with that round in place, the second in-wave sphere attempt (only 48 % of a hit wave's lanes
+//    take part) moves into it: one in-wave attempt, two in the packing round: 146.6.  A block
+//    whose tile lies inside the target then has ~366 stragglers for the 256 entries of the list
+//    (the rest finish in place), so each block watches its own count and returns to two in-wave
+//    attempts while its list would overflow: 146.3, and 121.6 at 300 px / 100 spp (always one:
+//    147.0 / 107.7; always two: 142.5 / 119.5).
 #pragma once
 
 #include "rf_kernels.h"
 
 namespace rf {
 
-// Measured at the headline config (G samples/s; 1 set = render_kernel_coop = 122): 2 sets 133,
-// 3 sets 138 (at 7 waves per SIMD; 135 at 6, 132 at 8 with heavy spilling), 4 sets 114.
-// Register spills are not affordable here even when they are cheap in time: every spilled dword
-// of a wave is 256 B of scratch traffic, and the first 3-set build moved 2.5x the algorithmic
-// HBM bytes.  The kernel therefore (a) re-derives the per-thread geometry inside the sample loop
-// from an index the compiler cannot see through, (b) moves block-uniform values that were
-// computed with vector instructions into scalar registers, (c) keeps the colour accumulators of
-// two of the three sets in LDS: 72 VGPRs, no scratch, traffic = algorithmic.
 #ifndef RF_SETS
 #define RF_SETS 3
 #endif
 #ifndef RF_SETS_OCC
-#define RF_SETS_OCC 7
+#define RF_SETS_OCC 7 // waves per SIMD the register allocator is held to
 #endif
 constexpr int kSets = RF_SETS;
-// Two packing rounds when the list needs more than one wave (measured, G samples/s, with two
-// in-wave sphere attempts: one round 140.7; one attempt per entry in round 1: 142.9; two: 141.7;
-// round 2 only above 128 entries: 140.0).  With the first packing round in place, the second
-// in-wave sphere attempt (48 % of the lanes) is better made there: one in-wave attempt and two
-// in round 1: 146.6 (three: 144.0) -- although an all-hit block then has ~366 stragglers for the
-// 256 entries of the list and the rest finish in place, which costs 10 % at 300 px where whole
-// tiles lie inside the target.  Hence the per-block switch in the kernel: 146.3 and, at 300 px /
-// 100 spp, 121.6 (always one attempt: 107.7, always two: 119.5).
 #ifndef RF_TWO_ROUNDS
 #define RF_TWO_ROUNDS 1
 #endif
 #ifndef RF_TWO_ROUNDS_MIN
-#define RF_TWO_ROUNDS_MIN 64
+#define RF_TWO_ROUNDS_MIN 64 // entries above which the packing round is used (128: 140.0 instead of 142.9)
 #endif
 #ifndef RF_R1_SPHERE
-#define RF_R1_SPHERE 2
+#define RF_R1_SPHERE 2 // attempts per entry in the packing round (1 / 3: 142.9 / 144.0 with one in-wave attempt)
 #endif
+#ifndef RF_R1_DISC
+#define RF_R1_DISC 1
+#endif
+#ifndef RF_COOP2_TRIPS
+#define RF_COOP2_TRIPS 1
+#endif
+constexpr int kCoopTrips2 = RF_COOP2_TRIPS; // in-wave sphere attempts before the cooperative call
 #ifndef RF_ADAPT_ON // hysteresis of the per-block switch between one and two in-wave sphere attempts
 #define RF_ADAPT_ON 32
 #endif
 #ifndef RF_ADAPT_OFF
 #define RF_ADAPT_OFF -32
 #endif
-#ifndef RF_COOP2_TRIPS
-#define RF_COOP2_TRIPS 1
-#endif
-constexpr int kCoopTrips2 = RF_COOP2_TRIPS; // in-wave sphere attempts before the cooperative call
-#ifndef RF_R1_DISC
-#define RF_R1_DISC 1
-#endif
 #ifndef RF_COOP_CAP
-#define RF_COOP_CAP kBlock // entries of the packed list; tests build a small one to force the overflow path
+#define RF_COOP_CAP kBlock // entries of the packed list; tests build a 32-entry one to stress the overflow path
 #endif
 constexpr int kCoopCap = RF_COOP_CAP;
 static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in CoopLds");
 #ifndef RF_COLOUR_LDS
-#define RF_COLOUR_LDS 2 // with the geometry / uniform tricks below: 72 VGPRs, no spills, 20.5 KB LDS
+#define RF_COLOUR_LDS 2
 #endif
 constexpr int kTileH2 = kTileH * kSets;
 
-// coop_finish for kSets pixel sets at once.  The packed list holds at most kBlock entries (the
-// LDS arrays of CoopLds); stragglers that would not fit -- more than a third of all lanes still
-// looking, which does not happen in practice -- finish their loop in their own wave instead.
-// Returns the number of stragglers the block had (block-uniform).
+// coop_finish for kSets pixel sets at once.  The packed list holds kCoopCap entries (the LDS
+// arrays of CoopLds); stragglers that do not fit finish their loop in their own wave.  Returns
+// the number of stragglers the block had (block-uniform).
 template <int DIM>
 __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
                                             uint32_t (&w)[kSets][6])
