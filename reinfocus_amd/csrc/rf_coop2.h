@@ -219,9 +219,11 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
     return stragglers;
 }
 
-template <bool POW2, int LENS>
+template <bool POW2, int LENS, int WX = kWavesX>
 __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
+    // tile of a block: WX waves (of kWaveW x kWaveH pixels) side by side, 4 / WX down, kSets sets
+    constexpr int tWavesX = WX, tTileW = WX * kWaveW, tTileH = (4 / WX) * kWaveH, tTileH2 = tTileH * kSets;
     __shared__ CoopLds lds;
     // the frame staging buffer (kSets * 768 B) reuses the words4 array once the sample loop is over
     static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock * 3, "stage does not fit");
@@ -241,11 +243,11 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     if (tid == 2)
         lds.cnt2 = 0;
     __syncthreads();
-    const int tiles_x = (a.w + kTileW - 1) / kTileW;
+    const int tiles_x = (a.w + tTileW - 1) / tTileW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const bool mirror = (2 * tile_x + 1) * kTileW > a.w; // see render_kernel_coop
+    const bool mirror = (2 * tile_x + 1) * tTileW > a.w; // see render_kernel_coop
 
-    // Pixel geometry of a thread.  Set j covers the rows kTileH * j further down.  All of it is
+    // Pixel geometry of a thread.  Set j covers the rows tTileH * j further down.  All of it is
     // cheap to derive from the thread index, and the sample loop derives it afresh every
     // iteration from an index the compiler cannot see through (Geometry::opaque): kept alive
     // across the loop these loop invariants -- x, y, their float forms as packed-math pairs,
@@ -259,17 +261,17 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             asm volatile("" : "+v"(v));
             return v;
         }
-        __device__ __forceinline__ int y_of(int j) const { return y0 + j * kTileH; }
+        __device__ __forceinline__ int y_of(int j) const { return y0 + j * tTileH; }
         __device__ __forceinline__ bool live_of(int j) const { return live_x && y_of(j) < h; }
     };
     auto geometry = [&](int t) {
         const int wv = t >> 6, lane = t & 63;
-        const int wx = mirror ? (kWavesX - 1 - wv % kWavesX) : (wv % kWavesX);
+        const int wx = mirror ? (tWavesX - 1 - wv % tWavesX) : (wv % tWavesX);
         Geometry r;
         r.col = wx * kWaveW + (lane % kWaveW);
-        r.row0 = (wv / kWavesX) * kWaveH + (lane / kWaveW);
-        r.x = tile_x * kTileW + r.col;
-        r.y0 = tile_y * kTileH2 + r.row0;
+        r.row0 = (wv / tWavesX) * kWaveH + (lane / kWaveW);
+        r.x = tile_x * tTileW + r.col;
+        r.y0 = tile_y * tTileH2 + r.row0;
         r.live_x = r.x < a.w;
         r.h = a.h;
         return r;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         const uint8_t g8 = (uint8_t)(cg[j] * a.scale);
         const uint8_t b8 = (uint8_t)(cb[j] * a.scale);
         if ((a.w & 3) == 0) {
-            const int slot = (j * kTileH + ge.row0) * kTileW + ge.col;
+            const int slot = (j * tTileH + ge.row0) * tTileW + ge.col;
             sb[slot * 3 + 0] = r8;
             sb[slot * 3 + 1] = g8;
             sb[slot * 3 + 2] = b8;
@@ -405,16 +407,16 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         }
     }
     if ((a.w & 3) == 0) {
-        // the tile's rows (kTileW * 3 B each) -> LDS -> coalesced dword stores per row
+        // the tile's rows (tTileW * 3 B each) -> LDS -> coalesced dword stores per row
         __syncthreads();
-        constexpr int kRowDw = kTileW * 3 / 4;
-        for (int i = tid; i < kTileH2 * kRowDw; i += kBlock) {
+        constexpr int kRowDw = tTileW * 3 / 4;
+        for (int i = tid; i < tTileH2 * kRowDw; i += kBlock) {
             const int r = i / kRowDw, d = i - r * kRowDw;
-            const int yy = tile_y * kTileH2 + r;
-            const int valid_dw = min(kTileW, a.w - tile_x * kTileW) * 3 / 4; // w % 4 == 0
+            const int yy = tile_y * tTileH2 + r;
+            const int valid_dw = min(tTileW, a.w - tile_x * tTileW) * 3 / 4; // w % 4 == 0
             if (yy < a.h && d < valid_dw) {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(
-                    a.frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * kTileW) * 3);
+                    a.frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * tTileW) * 3);
                 dst[d] = stage[r * kRowDw + d];
             }
         }
