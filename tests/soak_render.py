@@ -1,5 +1,5 @@
-"""Development tool: randomised parity soak of the render + focus path against the CPU oracle
-(test infrastructure use of oracle/, like tests/).  usage: python tools/soak.py [cases] [seed]"""
+"""TEST INFRASTRUCTURE (not collected by pytest): randomised parity soak of the render + focus path
+against the CPU oracle.  usage (GPU box, repo root): python tests/soak_render.py [cases] [seed]"""
 import sys
 import time
 
