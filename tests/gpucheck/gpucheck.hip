@@ -33,7 +33,8 @@ extern "C" int gc_check_sqrt_rcp(unsigned long long out[3])
     unsigned long long *d_bad;
     if (hipMalloc((void **)&d_bad, 16) != hipSuccess)
         return -1;
-    hipMemset(d_bad, 0, 16);
+    if (hipMemset(d_bad, 0, 16) != hipSuccess)
+        return -1;
     // every positive float from 2^-101 to 2^101 (covers the accepted range and its edges)
     const uint32_t lo = 0x0D000000u, hi = 0x72000000u;
     unsigned long long total = 0;
@@ -44,8 +45,9 @@ extern "C" int gc_check_sqrt_rcp(unsigned long long out[3])
     }
     if (hipDeviceSynchronize() != hipSuccess)
         return -2;
-    hipMemcpy(out, d_bad, 16, hipMemcpyDeviceToHost);
+    if (hipMemcpy(out, d_bad, 16, hipMemcpyDeviceToHost) != hipSuccess)
+        return -3;
     out[2] = total;
-    hipFree(d_bad);
+    (void)hipFree(d_bad);
     return 0;
 }
