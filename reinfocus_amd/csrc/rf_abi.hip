@@ -77,6 +77,8 @@ struct rf_ctx {
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
     bool two_sets = true; // several pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
+    int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..3 forces one (experiments), -1: pick_tile_layout
+    double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
 
     uint8_t *d_frames = nullptr;
@@ -175,6 +177,35 @@ void drop_env_graph(rf_ctx *ctx)
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Tile layout of render_kernel_coop2 for a frame size (index into the table in launch_render):
+//   0: 128 x 6 (4 waves of 32 x 2 side by side)   1: 64 x 12 (2 x 2 such waves)
+//   2: 256 x 3 (4 waves of 64 x 1)                3: 128 x 6 (2 x 2 waves of 64 x 1)
+// Cost model fitted to tools/ablayout.sh (G samples/s at 128 / 256 / 300 / 384 / 512 / 600 px):
+// time ~ padded area x shape factor x (1 + 0.35 x share of tile columns that lie entirely
+// inside the target).  Such tiles have more stragglers than the 256-entry cooperative list holds
+// and fall back to two in-wave sphere attempts; 64 x 1 waves are cut more often by the target's
+// vertical edges (factor 1.045).  `hit_fraction` = width of the target / width of the frame.
+int pick_tile_layout(int h, int w, double hit_fraction)
+{
+    static const int tile_w[4] = {128, 64, 256, 128}, tile_h[4] = {2 * rf::kSets, 4 * rf::kSets, rf::kSets, 2 * rf::kSets};
+    static const double shape[4] = {1.0, 1.0, 1.045, 1.048};
+    const double lo = 0.5 * (1.0 - hit_fraction) * w, hi = 0.5 * (1.0 + hit_fraction) * w;
+    int best = 0;
+    double best_cost = 0.0;
+    for (int l = 0; l < 4; ++l) {
+        const int cols = (w + tile_w[l] - 1) / tile_w[l], rows = (h + tile_h[l] - 1) / tile_h[l];
+        int inside = 0;
+        for (int c = 0; c < cols; ++c)
+            inside += (c * tile_w[l] >= lo && (c + 1) * tile_w[l] <= hi) ? 1 : 0;
+        const double cost = (double)cols * tile_w[l] * rows * tile_h[l] * shape[l] * (1.0 + 0.35 * inside / cols);
+        if (l == 0 || cost < best_cost) {
+            best = l;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 // Splits the lens radius for rf_math.h lens_offset and decides -- by trying every float32 a disc
 // coordinate can be (multiples of 2^-24 in [-1, 0), of 2^-23 in [0, 1]) -- whether the float32
 // form reproduces float32(float64(p) * radius) for this radius.  ~60 ms on one core; remembered
@@ -268,6 +299,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->two_sets = v[0] != '1';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))
         ctx->env_graph_enabled = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
+        ctx->tile_layout = (v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : -1;
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
 
@@ -423,6 +456,13 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
     }
     ctx->axis = axis;
     ctx->scene_n = n;
+    // width of the target in the frame (for the tile layout): |p.x| <= half at the rectangle's
+    // plane <=> s within half * |ll.z| / (|z| * horizontal.x) of the centre
+    {
+        const double half = rect[0], z = rect[1], llz = cam_dyn[2], hx = cam_dyn[3];
+        const double f = (z != 0.0 && hx != 0.0) ? fabs(2.0 * half * llz / (z * hx)) : 0.658;
+        ctx->hit_fraction = (f == f && f > 0.0 && f < 1.0) ? f : (f >= 1.0 ? 1.0 : 0.658);
+    }
     return RF_OK;
 }
 
@@ -468,24 +508,25 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             b.n = ne;
             const dim3 grid(gx, ne), block(rf::kBlock);
             const dim3 tiles(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH - 1) / rf::kTileH), ne);
-            const dim3 tiles2(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH2 - 1) / rf::kTileH2), ne);
-            // Tiles are 128 x 6 pixels (four wave columns) or 64 x 12 (two columns, two wave rows).  The
-            // wide layout is ~10 % faster per covered pixel (measured at 256 px: 140 against 124 G
-            // samples/s) but may cover many pixels that are not there: at 300 px it pads to 384
-            // columns, the narrow one to 320 (122 against 132).  Take the one with the smaller cost.
-            const int th_wide = rf::kTileH2, th_narrow = 2 * rf::kTileH2;
-            const long cover_wide = (long)((w + 127) / 128 * 128) * ((h + th_wide - 1) / th_wide * th_wide);
-            const long cover_narrow = (long)((w + 63) / 64 * 64) * ((h + th_narrow - 1) / th_narrow * th_narrow);
-            const bool narrow = cover_narrow * 11 < cover_wide * 10;
-            const dim3 tiles2n(((w + 63) / 64) * ((h + th_narrow - 1) / th_narrow), ne);
+            // A block's tile is WX waves of WW x 64/WW pixels side by side, 4/WX down, kSets sets:
+            //   A 128 x 6  (WX 4, WW 32)   B 64 x 12 (2, 32)   C 256 x 3 (4, 64)   D 128 x 6 (2, 64)
+            // see pick_tile_layout.
+            const int layout = ctx->tile_layout >= 0 ? ctx->tile_layout : pick_tile_layout(h, w, ctx->hit_fraction);
+            static const int kLayoutW[4] = {128, 64, 256, 128},
+                             kLayoutH[4] = {2 * rf::kSets, 4 * rf::kSets, rf::kSets, 2 * rf::kSets};
+            const dim3 tiles2(((w + kLayoutW[layout] - 1) / kLayoutW[layout]) *
+                                  ((h + kLayoutH[layout] - 1) / kLayoutH[layout]),
+                              ne);
             const bool lens32 = a.cs.lens_f32 != 0;
             if (axis && ctx->coop && ctx->two_sets) {
-#define RF_LAUNCH2(P, L)                                                                              \
-    do {                                                                                              \
-        if (narrow)                                                                                   \
-            hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2>), tiles2n, block, 0, ctx->stream, b); \
-        else                                                                                          \
-            hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4>), tiles2, block, 0, ctx->stream, b);  \
+#define RF_LAUNCH2(P, L)                                                                                   \
+    do {                                                                                                   \
+        switch (layout) {                                                                                  \
+        case 0: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 32>), tiles2, block, 0, ctx->stream, b); break; \
+        case 1: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 32>), tiles2, block, 0, ctx->stream, b); break; \
+        case 2: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 64>), tiles2, block, 0, ctx->stream, b); break; \
+        default: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 64>), tiles2, block, 0, ctx->stream, b); break; \
+        }                                                                                                  \
     } while (0)
                 if (pow2 && lens32)
                     RF_LAUNCH2(true, 1);
@@ -842,6 +883,11 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
                             0.0f,              0.0f,              0};
     lens_split(ctx->cs);
     // canonical frame -> horizontal = (h2, +0, +0), vertical = (+0, v2, +0): the AXIS kernels apply
+    // the target's half side is target * tan_half_r at distance target; the frame's half width at
+    // that distance is target * half_width (camera.py:147-160, world.py:114-116)
+    ctx->hit_fraction = (cfg->half_width > 0.0 && cfg->tan_half_r > 0.0 && cfg->tan_half_r < cfg->half_width)
+                            ? cfg->tan_half_r / cfg->half_width
+                            : (cfg->tan_half_r >= cfg->half_width ? 1.0 : 0.658);
     ctx->env_axis = cfg->look_from[0] == 0.0f && cfg->look_from[1] == 0.0f && cfg->look_from[2] == 0.0f &&
                     cfg->cam_u[0] == 1.0f && cfg->cam_u[1] == 0.0f && cfg->cam_u[2] == 0.0f &&
                     cfg->cam_v[0] == 0.0f && cfg->cam_v[1] == 1.0f && cfg->cam_v[2] == 0.0f &&

@@ -219,11 +219,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
     return stragglers;
 }
 
-template <bool POW2, int LENS, int WX = kWavesX>
+template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW>
 __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
-    // tile of a block: WX waves (of kWaveW x kWaveH pixels) side by side, 4 / WX down, kSets sets
-    constexpr int tWavesX = WX, tTileW = WX * kWaveW, tTileH = (4 / WX) * kWaveH, tTileH2 = tTileH * kSets;
+    // tile of a block: WX waves (of WW x 64 / WW pixels) side by side, 4 / WX down, kSets sets
+    constexpr int tWaveW = WW, tWaveH = 64 / WW;
+    constexpr int tWavesX = WX, tTileW = WX * tWaveW, tTileH = (4 / WX) * tWaveH, tTileH2 = tTileH * kSets;
     __shared__ CoopLds lds;
     // the frame staging buffer (kSets * 768 B) reuses the words4 array once the sample loop is over
     static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock * 3, "stage does not fit");
@@ -268,8 +269,8 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         const int wv = t >> 6, lane = t & 63;
         const int wx = mirror ? (tWavesX - 1 - wv % tWavesX) : (wv % tWavesX);
         Geometry r;
-        r.col = wx * kWaveW + (lane % kWaveW);
-        r.row0 = (wv / tWavesX) * kWaveH + (lane / kWaveW);
+        r.col = wx * tWaveW + (lane % tWaveW);
+        r.row0 = (wv / tWavesX) * tWaveH + (lane / tWaveW);
         r.x = tile_x * tTileW + r.col;
         r.y0 = tile_y * tTileH2 + r.row0;
         r.live_x = r.x < a.w;
