@@ -1012,20 +1012,34 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             }
             uint8_t *st = ctx->h_stage;
             if (!ctx->env_graph) {
+                // Capture problems are not the caller's problem: the step then simply keeps being
+                // enqueued call by call (same kernels, same results).
                 hipGraph_t captured = nullptr;
-                RF_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                int rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
+                hipError_t he = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+                int rc = RF_OK;
+                if (he == hipSuccess) {
+                    rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
                                           (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
-                const hipError_t end = hipStreamEndCapture(ctx->stream, &captured);
-                if (rc != RF_OK) {
+                    he = hipStreamEndCapture(ctx->stream, &captured);
+                    if (he == hipSuccess && rc == RF_OK)
+                        he = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
                     if (captured)
                         (void)hipGraphDestroy(captured);
-                    return rc;
                 }
-                RF_HIP(end);
-                const hipError_t inst = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(captured);
-                RF_HIP(inst);
+                if (he != hipSuccess || rc != RF_OK || !ctx->env_graph) {
+                    (void)hipGetLastError();
+                    ctx->env_graph = nullptr;
+                    ctx->env_graph_enabled = false;
+                    rc = enqueue_env_step(ctx, host_actions, host_pool, host_obs, host_rewards, host_truncated, &k);
+                    if (rc != RF_OK)
+                        return rc;
+                    RF_HIP(hipGetLastError());
+                    RF_HIP(hipStreamSynchronize(ctx->stream));
+                    ctx->env_steps += 1;
+                    if (host_n_reset)
+                        *host_n_reset = k;
+                    return RF_OK;
+                }
             }
             memcpy(st, host_actions, (size_t)n * 4);
             memcpy(st + o_pool, host_pool, (size_t)n * 8);
