@@ -109,6 +109,26 @@ def pmc_bytes_per_pixel():
     return None, None
 
 
+def pmc_valu_summary():
+    """VALU-side figures of the render kernel from the same PMC summary (the kernel is bound by
+    vector-ALU issue, not by HBM): instructions per wave and per 64 pixels, lane utilisation, SIMD
+    cycles available per VALU instruction issued."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    for name, e in json.load(open(files[-1])).items():
+        if "render_kernel" in name and e.get("valu_insts_per_wave"):
+            per_wave = float(e.get("pixels_per_wave", 64))
+            return {"insts_per_wave": e["valu_insts_per_wave"],
+                    "insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / per_wave,
+                    "lane_utilisation": e.get("valu_lane_utilisation"),
+                    "simd_cycles_per_inst": e.get("simd_cycles_per_valu_inst"),
+                    "source": os.path.basename(files[-1])}
+    return None
+
+
 def shard_plan(rank, envs_per_gpu, frame):
     """Rank r owns global envs [r*E, (r+1)*E) and therefore the RNG states a single-device
     run of all envs would use for them (pixel index = e*h*w + y*w + x, render.py:217)."""
@@ -254,6 +274,7 @@ def main(argv=None):
                 "avg_launch_ms": timing["render_ms"] / max(timing["render_launches"], 1),
                 "launches": timing["render_launches"],
                 "samples_per_s": pixels * spp / render_s,
+                "valu": pmc_valu_summary(),
                 "note": "VALU-bound by construction (64-bit xoroshiro128+ draws and rejection loops fixed "
                         "by parity): see DESIGN.md section Roofline",
             }

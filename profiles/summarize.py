@@ -46,6 +46,10 @@ def main(tag):
             e["pixels_per_wave"] = 192 if "render_kernel_coop2" in k else 64
         if "SQ_INSTS_VALU" in e and e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+        # SIMD cycles the kernel had per VALU instruction it issued (GRBM_GUI_ACTIVE counts every XCD's
+        # cycles; 1024 SIMDs): ~3.3 means the vector ALUs are saturated by this instruction mix
+        if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_INSTS_VALU"):
+            e["simd_cycles_per_valu_inst"] = e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / e["SQ_INSTS_VALU"]
         if "SQ_THREAD_CYCLES_VALU" in e and e.get("SQ_ACTIVE_INST_VALU"):
             e["valu_lane_utilisation"] = e["SQ_THREAD_CYCLES_VALU"] / (e["SQ_ACTIVE_INST_VALU"] * 64)
         out[k] = e
