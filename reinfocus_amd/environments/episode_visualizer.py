@@ -61,90 +61,104 @@ def resize_linear_u8(image, width, height):
 class HistoryVisualizer:
     """Stacks one row per environment: the 600 px rendering on the left, a plot of the last
     `history_length` focus positions / focus values on the right
-    (episode_visualizer.py:84-301; same constructor arguments)."""
+    (episode_visualizer.py:84-301; same constructor arguments).
+
+    The plots are built on matplotlib's object API with an Agg canvas of their own (no pyplot
+    state, nothing to close), one helper per plot element."""
+
+    FRAME = 600  # pixels: height of a row and side of the rendering (episode_visualizer.py:197, :206)
 
     def __init__(self, num_envs, target_index, focus_plane_index, focus_value_index, renderer, limits,
                  ender=None, history_length=10, target_radius=None):
-        self._num_envs = num_envs
-        self._target_index = target_index
-        self._focus_plane_index = focus_plane_index
-        self._focus_value_index = focus_value_index
-        self._limits = limits
-        self._history_length = history_length
-        self._target_radius = target_radius
-        self._ender = ender
         self._renderer = renderer
-
+        self._ender = ender
+        self._limits = limits
+        self._target_radius = target_radius
+        self._history_length = history_length
+        self._num_envs = num_envs
+        self._columns = {"target": target_index, "plane": focus_plane_index, "value": focus_value_index}
         self._current_moves = np.zeros(num_envs, dtype=np.int32)
         self._targets = np.zeros(num_envs, dtype=np.float32)
         self._move_histories = histories.Histories(num_envs, history_length)
         self._focus_histories = histories.Histories(num_envs, history_length)
 
+    # -- bookkeeping ------------------------------------------------------------------------------
+    def _selection(self, indices):
+        return np.full(self._num_envs, True) if indices is None else indices
+
+    def _record(self, states, observations, selected):
+        self._move_histories.append_events(states[:, self._columns["plane"]], selected)
+        self._focus_histories.append_events(observations[:, self._columns["value"]], selected)
+
     def step(self, states, observations, indices=None):
         """One timestep of the selected environments (episode_visualizer.py:133-155)."""
-        if indices is None:
-            indices = np.full(self._num_envs, True)
-        self._current_moves[indices] += 1
-        self._move_histories.append_events(states[:, self._focus_plane_index], indices)
-        self._focus_histories.append_events(observations[:, self._focus_value_index], indices)
+        selected = self._selection(indices)
+        self._current_moves[selected] += 1
+        self._record(states, observations, selected)
 
     def reset(self, states, observations, indices=None):
-        """The selected environments started new episodes (episode_visualizer.py:157-185)."""
-        if indices is None:
-            indices = np.full(self._num_envs, True)
-        self._current_moves[indices] = 0
-        self._targets[indices] = states[:, self._target_index]
-        self._move_histories.reset(indices)
-        self._move_histories.append_events(states[:, self._focus_plane_index], indices)
-        self._focus_histories.reset(indices)
-        self._focus_histories.append_events(observations[:, self._focus_value_index], indices)
+        """The selected environments started new episodes (episode_visualizer.py:157-185).  The
+        reference appends the first focus value to every history here (:185), which only works
+        while all environments reset together; this appends to the selected ones."""
+        selected = self._selection(indices)
+        self._current_moves[selected] = 0
+        self._targets[selected] = states[:, self._columns["target"]]
+        self._move_histories.reset(selected)
+        self._focus_histories.reset(selected)
+        self._record(states, observations, selected)
 
+    # -- drawing ----------------------------------------------------------------------------------
     def visualize(self):
-        """uint8[num_envs * 600, 600 + graph width, 3] (episode_visualizer.py:188-201)."""
-        renderings = np.asarray(self._renderer.render(600))
-        graphs = [self._visualize_single_history(i) for i in range(self._num_envs)]
-        return np.concatenate([np.concatenate([r, g], axis=1) for r, g in zip(renderings, graphs)], axis=0)
+        """uint8[num_envs * 600, 600 + plot width, 3] (episode_visualizer.py:188-201)."""
+        frames = np.asarray(self._renderer.render(self.FRAME))
+        rows = [np.concatenate([frames[i], self._visualize_single_history(i)], axis=1)
+                for i in range(self._num_envs)]
+        return np.concatenate(rows, axis=0)
 
-    def _visualize_single_history(self, env_index, frame_height=600):
-        """The performance plot of one environment (episode_visualizer.py:203-301)."""
+    def _caption(self, env_index):
+        caption = f"focus position {self._current_moves[env_index]}\n"
+        return caption + (self._ender.status(env_index) if self._ender is not None else "")
+
+    def _draw_target(self, axes, target):
+        axes.axvline(x=target, linestyle=":", color="darkorange", label="target")
+        radius = self._target_radius
+        if radius is not None and radius > 0.0:
+            axes.axvspan(target - radius, target + radius, edgecolor="darkorange", facecolor=("darkorange", 0.1),
+                         linestyle=(0, (5, 10)))
+
+    def _draw_trail(self, axes, moves, values):
+        """The remembered (position, value) points, oldest palest, joined by curved arrows."""
         import matplotlib
 
-        matplotlib.use("Agg", force=False)
-        from matplotlib import pyplot
+        count = len(values)
+        shades = fading_colours(matplotlib.colormaps["Blues"], self._history_length, count)
+        points = list(zip(moves, values))
+        for order, (point, shade) in enumerate(zip(points, shades)):
+            axes.plot(*point, color=shade, zorder=order, marker=".", label="focus" if order == count - 1 else "")
+            if order:
+                axes.annotate("", xy=point, xytext=points[order - 1], xycoords="data", textcoords="data",
+                              arrowprops=dict(arrowstyle="->", color=shade, shrinkA=5, shrinkB=5,
+                                              connectionstyle="arc3,rad=0.1"))
 
-        focus_history = self._focus_histories.get_history(env_index)
-        move_history = self._move_histories.get_history(env_index)
-        target = self._targets[env_index]
-        n_focus_history = len(focus_history)
+    def _visualize_single_history(self, env_index, frame_height=None):
+        """The performance plot of one environment (episode_visualizer.py:203-301), scaled to the
+        height of a row."""
+        from matplotlib.backends.backend_agg import FigureCanvasAgg
+        from matplotlib.figure import Figure
 
-        figure, axes = pyplot.subplots()
+        frame_height = self.FRAME if frame_height is None else frame_height
+        figure = Figure()  # rcParams size and dpi, as pyplot.subplots() in the reference
+        canvas = FigureCanvasAgg(figure)
+        axes = figure.add_subplot()
         axes.set_xlim(*self._limits)
         axes.set_ylim(-1.0, 1.0)
-        x_label = f"focus position {self._current_moves[env_index]}\n"
-        if self._ender is not None:
-            x_label += self._ender.status(env_index)
-        axes.set_xlabel(x_label)
+        axes.set_xlabel(self._caption(env_index))
         axes.set_ylabel("focus value")
-        axes.axvline(x=target, linestyle=":", color="darkorange", label="target")
-        if self._target_radius is not None and self._target_radius > 0.0:
-            axes.axvspan(target - self._target_radius, target + self._target_radius, edgecolor="darkorange",
-                         facecolor=("darkorange", 0.1), linestyle=(0, (5, 10)))
-
-        fading_blues = fading_colours(matplotlib.colormaps["Blues"], self._history_length, n_focus_history)
-        previous = None
-        for i, move_and_focus in enumerate(zip(move_history, focus_history)):
-            colour = fading_blues[i]
-            axes.plot(*move_and_focus, color=colour, zorder=i, marker=".",
-                      label="focus" if i == n_focus_history - 1 else "")
-            if previous is not None:
-                axes.annotate("", xy=move_and_focus, xycoords="data", xytext=previous, textcoords="data",
-                              arrowprops={"arrowstyle": "->", "color": colour, "shrinkA": 5, "shrinkB": 5,
-                                          "connectionstyle": "arc3,rad=0.1"})
-            previous = move_and_focus
-
+        self._draw_target(axes, self._targets[env_index])
+        self._draw_trail(axes, self._move_histories.get_history(env_index),
+                         self._focus_histories.get_history(env_index))
         figure.legend(loc="lower right")
         figure.tight_layout()
-        figure.canvas.draw()
-        image = np.array(figure.canvas.buffer_rgba())[:, :, :3]
-        pyplot.close(figure)
-        return resize_linear_u8(image, int(frame_height * image.shape[1] / image.shape[0]), frame_height)
+        canvas.draw()
+        plot = np.asarray(canvas.buffer_rgba())[:, :, :3]
+        return resize_linear_u8(plot, int(frame_height * plot.shape[1] / plot.shape[0]), frame_height)

@@ -42,43 +42,58 @@ except ImportError:
 _VECTOR_ENVIRONMENTS = (harness.VectorDiscreteSteps, harness.DeviceVectorDiscreteSteps)
 
 
+def _how_many(indices, num_envs):
+    """Number of member environments `indices` (None, an int or an iterable of ints) selects."""
+    if indices is None:
+        return num_envs
+    if isinstance(indices, int):
+        return 1
+    if isinstance(indices, Iterable):
+        return sum(1 for _ in indices)
+    return num_envs
+
+
 class SB3Wrapper(_VecEnvBase):
+    """stable-baselines3 VecEnv over one vector environment of this package
+    (vector_shim.py:20-184)."""
+
     def __init__(self, env, render_mode):
-        """vector_shim.py:25-46: only this package's vector environments are accepted."""
-        if not isinstance(env, _VECTOR_ENVIRONMENTS):
+        if not isinstance(env, _VECTOR_ENVIRONMENTS):  # vector_shim.py:32-33
             raise NotImplementedError
-        self._env = env
         super().__init__(env.num_envs, env.single_observation_space, env.single_action_space)
+        self._env = env
+        self._pending_actions = None
         self.render_mode = render_mode
-        self._actions = None
+
+    # -- stepping -------------------------------------------------------------------------------
+    def reset(self):
+        observations, _info = self._env.reset()
+        return observations
 
     def step_async(self, actions):
-        self._actions = actions
-
-    def reset(self):
-        return self._env.reset()[0]
+        self._pending_actions = actions
 
     def step_wait(self):
-        """vector_shim.py:63-93.  The environments reset themselves inside step(), so -- as in
-        the reference -- "terminal_observation" is the observation step() returned for that
+        """vector_shim.py:63-93.  The environments reset themselves inside step(), so -- as in the
+        reference -- "terminal_observation" is the observation step() returned for that
         environment, i.e. already the first one of its next episode."""
-        assert self._actions is not None
-        obs, rewards, terminated, truncated, info_dict = self._env.step(self._actions)
+        assert self._pending_actions is not None
+        observations, rewards, terminated, truncated, info = self._env.step(self._pending_actions)
         dones = terminated | truncated
-        infos = []
-        for i in range(self.num_envs):
-            infos.append({key: value[i] for key, value in info_dict.items() if isinstance(value, np.ndarray)})
-            if dones[i]:
-                infos[i]["terminal_observation"] = obs[i]
-        return obs, rewards, dones, infos
+        per_env_keys = [key for key, value in info.items() if isinstance(value, np.ndarray)]
+        infos = [{key: info[key][i] for key in per_env_keys} for i in range(self.num_envs)]
+        for i in np.flatnonzero(dones):
+            infos[i]["terminal_observation"] = observations[i]
+        return observations, rewards, dones, infos
 
     def close(self):
         self._env.close()
 
+    # -- attribute / method plumbing stable-baselines3 expects ------------------------------------
     def get_attr(self, attr_name, indices=None):
-        if hasattr(self._env, attr_name):
-            return [getattr(self._env, attr_name)] * self._get_result_length(indices)
-        raise NotImplementedError(f"{attr_name}, {indices}")
+        if not hasattr(self._env, attr_name):
+            raise NotImplementedError(f"{attr_name}, {indices}")
+        return [getattr(self._env, attr_name)] * _how_many(indices, self._env.num_envs)
 
     def set_attr(self, attr_name, value, indices=None):
         raise NotImplementedError(f"{attr_name}, {value}, {indices}")
@@ -87,14 +102,7 @@ class SB3Wrapper(_VecEnvBase):
         raise NotImplementedError(f"{method_name}, {method_args}, {indices}, {method_kwargs}")
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * self._get_result_length(indices)
-
-    def _get_result_length(self, indices):
-        if isinstance(indices, int):
-            return 1
-        if isinstance(indices, Iterable):
-            return len(list(indices))
-        return self._env.num_envs
+        return [False] * _how_many(indices, self._env.num_envs)
 
     def get_images(self):
         return [self._env.render()]
