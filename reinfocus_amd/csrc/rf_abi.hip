@@ -180,6 +180,7 @@ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Tile layout of render_kernel_coop2 for a frame size (index into the table in launch_render):
 //   0: 128 x 6 (4 waves of 32 x 2 side by side)   1: 64 x 12 (2 x 2 such waves)
 //   2: 256 x 3 (4 waves of 64 x 1)                3: 128 x 6 (2 x 2 waves of 64 x 1)
+//   4: 64 x 12 (4 waves of 16 x 4 side by side)   5: 32 x 24 (2 x 2 such waves; experiments only)
 // Cost model fitted to tools/ablayout.sh (G samples/s at 128 / 256 / 300 / 384 / 512 / 600 px):
 // time ~ padded area x shape factor x (1 + 0.35 x share of tile columns that lie entirely
 // inside the target).  Such tiles have more stragglers than the 256-entry cooperative list holds
@@ -203,6 +204,11 @@ int pick_tile_layout(int h, int w, double hit_fraction)
             best_cost = cost;
         }
     }
+    // 64 x 12 tiles of 16 x 4 pixel waves (layout 4) behave like layout 1 (within 2 % from 64 to 600
+    // px) except around 128 px, where the narrower waves fit the target's edges better: 130.5
+    // against 126 for layouts 0 / 1 / 3
+    if (w > 64 && w <= 128 && (best == 0 || best == 1))
+        return 4;
     return best;
 }
 
@@ -300,7 +306,7 @@ int rf_create(int device, rf_ctx **out)
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))
         ctx->env_graph_enabled = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
-        ctx->tile_layout = (v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : -1;
+        ctx->tile_layout = (v[0] >= '0' && v[0] <= '5') ? v[0] - '0' : -1;
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
 
@@ -512,8 +518,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             //   A 128 x 6  (WX 4, WW 32)   B 64 x 12 (2, 32)   C 256 x 3 (4, 64)   D 128 x 6 (2, 64)
             // see pick_tile_layout.
             const int layout = ctx->tile_layout >= 0 ? ctx->tile_layout : pick_tile_layout(h, w, ctx->hit_fraction);
-            static const int kLayoutW[4] = {128, 64, 256, 128},
-                             kLayoutH[4] = {2 * rf::kSets, 4 * rf::kSets, rf::kSets, 2 * rf::kSets};
+            static const int kLayoutW[6] = {128, 64, 256, 128, 64, 32},
+                             kLayoutH[6] = {2 * rf::kSets, 4 * rf::kSets, rf::kSets, 2 * rf::kSets, 4 * rf::kSets, 8 * rf::kSets};
             const dim3 tiles2(((w + kLayoutW[layout] - 1) / kLayoutW[layout]) *
                                   ((h + kLayoutH[layout] - 1) / kLayoutH[layout]),
                               ne);
@@ -525,7 +531,9 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         case 0: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 32>), tiles2, block, 0, ctx->stream, b); break; \
         case 1: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 32>), tiles2, block, 0, ctx->stream, b); break; \
         case 2: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 64>), tiles2, block, 0, ctx->stream, b); break; \
-        default: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 64>), tiles2, block, 0, ctx->stream, b); break; \
+        case 3: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 64>), tiles2, block, 0, ctx->stream, b); break; \
+        case 4: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 16>), tiles2, block, 0, ctx->stream, b); break; \
+        default: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 16>), tiles2, block, 0, ctx->stream, b); break; \
         }                                                                                                  \
     } while (0)
                 if (pow2 && lens32)
