@@ -1,25 +1,31 @@
 """Headline benchmark: vectorised env-steps/s of DiscreteSteps-v0 on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one VectorDiscreteSteps.step(actions) over this rank's environments: host
-transform / ender / reward (numpy), scene upload, the render kernel, the focus kernel, an
-8 B/env D2H and the same-step partial render of the environments that just ended
-(SURVEY.md section 8(d)).  Workload = BASELINE.json configs[2]: 4096 envs x 256x256 x 16 spp
-per GPU; with N > 1 every rank owns 4096 more envs (weak scaling, BASELINE configs[3]) and
-its own slice of the RNG state sequence.  There is no data-path collective: environments are
-independent, ranks only meet at the timing barriers (gloo, host side).
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: before anything
+touches the GPU it starts N fresh children of itself (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's JSON line and exits with the worst
+child's code.  Under an external launcher (python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...) it is one of the ranks.
+
+A "step" is one VectorDiscreteSteps.step(actions) over this rank's environments: transform /
+enders / rewards, scene packing, the render kernel, the focus kernel, an 8 B/env D2H and the
+same-step partial render of the environments that just ended.
+Workload = BASELINE.json configs[2]: 4096 envs x 256x256 x 16 spp per GPU; with N > 1 every rank
+owns 4096 more envs (weak scaling, BASELINE configs[3]) and its own slice of the RNG state
+sequence.  There is no data-path collective: environments are independent, ranks only meet at
+the timing barriers (gloo, host side).  --sharded-env measures the product-level object instead
+(harness.ShardedVectorDiscreteSteps: one process, one rf_ctx + one host thread per GPU).
 
 Prints ONE JSON line (rank 0).  value = all ranks' env-steps / max-over-ranks seconds, with
-inputs resident in HBM (the only per-step host traffic is 44 B/env of scene parameters in
-and 8 B/env of focus values out, both inside the timed region).
+inputs resident in HBM (the only per-step host traffic is 4 + 8 B/env of actions and candidate
+reset states in and 29 B/env of observations, rewards and flags out, inside the timed region).
 """
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,6 +38,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 RENDER_BYTES_PER_PIXEL = 35  # 16 B state read + 16 B state write + 3 B frame write
 FOCUS_BYTES_PER_PIXEL = 3    # frame read
+VALU_ISSUE_PEAK = 0.5        # wave64 VALU instructions per cycle per SIMD (2 cycles each), same guide
 
 
 def parse_args(argv=None):
@@ -42,10 +49,13 @@ def parse_args(argv=None):
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--frame", type=int, default=256)
     ap.add_argument("--spp", type=int, default=16)
-    ap.add_argument("--cpu-baseline-envs", type=int, default=0, help="0 = choose ~15 s of CPU work")
+    ap.add_argument("--cpu-baseline-envs", type=int, default=0, help="0 = choose ~12 s of CPU work")
     ap.add_argument("--env", choices=["device", "host"], default="device",
                     help="device: whole step resident on the GPU (rf_env_*); host: numpy glue around "
                          "rf_render / rf_focus (identical results, tests/test_gpu_environment.py)")
+    ap.add_argument("--sharded-env", action="store_true",
+                    help="one process: harness.ShardedVectorDiscreteSteps over --gpus devices (threads), instead "
+                         "of one process per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="no per-kernel HIP events (and no roofline object): lets small configurations replay "
@@ -55,16 +65,70 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------
+# launching the ranks (parent process: nothing here may touch the GPU)
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(world, argv):
+    """Starts `world` children of this script, one rank per GPU, relays rank 0's stdout (the JSON
+    line) and returns the worst exit code.  A rank that fails takes the others down with it (they
+    would wait for it at the next barrier): they are ended by PID, never by pattern."""
+    port = free_port()
+    children = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if rank == 0 else sys.stderr
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                         stdout=out, cwd=os.getcwd()))
+    import threading
+
+    def relay(pipe):
+        for line in iter(pipe.readline, b""):
+            sys.stdout.write(line.decode("utf-8", "replace"))
+            sys.stdout.flush()
+
+    pump = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
+    pump.start()
+    worst = 0
+    pending = set(range(world))
+    failed_at = None
+    while pending:
+        for rank in sorted(pending):
+            rc = children[rank].poll()
+            if rc is None:
+                continue
+            pending.discard(rank)
+            if rc != 0:
+                print(f"bench.py: rank {rank} exited with code {rc}", file=sys.stderr)
+                worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+                failed_at = failed_at or time.monotonic()
+        if failed_at is not None and pending and time.monotonic() - failed_at > 10.0:
+            for rank in pending:  # the survivors are stuck at a barrier
+                children[rank].terminate()
+            failed_at = time.monotonic() + 3600.0
+        time.sleep(0.05)
+    pump.join(timeout=5.0)
+    return worst if 0 <= worst < 256 else 1
+
+
 class Ranks:
     """Host-side rendezvous of the one-process-per-GPU ranks (gloo; no GPU tensors)."""
 
-    def __init__(self, gpus):
+    def __init__(self, gpus, single_process=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != gpus:
-            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run "
-                             f"--nproc-per-node {gpus}")
+        self.world = 1 if single_process else int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != gpus and not single_process:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
@@ -91,42 +155,57 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def pmc_bytes_per_pixel():
-    """HBM bytes per rendered pixel of the render kernel from the committed rocprofv3 PMC
-    passes (profiles/<tag>_pmc.json: FETCH_SIZE doubled for gfx950's wide-read under-count,
-    WRITE_SIZE as is, divided by SQ_WAVES * pixels per wave; partial tiles at the frame's edge count
-    as whole ones: 258 instead of 256 rows at the headline size).  None if no profile is present."""
+# ---------------------------------------------------------------------------------------------
+# figures taken from the committed rocprofv3 PMC summary (profiles/<tag>_pmc.json)
+# ---------------------------------------------------------------------------------------------
+def committed_profile(kernel, frame, spp):
+    """The newest committed PMC summary (by round tag) that was collected for exactly this kernel
+    instance at this frame size and sample count, or (None, reason).  These figures are NOT measured
+    by the run that prints them; they are marked as such wherever they appear."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True)
     if not files:
-        return None, None
-    data = json.load(open(files[-1]))
-    for name, e in data.items():
-        if "render_kernel" in name and e.get("SQ_WAVES") and "hbm_read_bytes_corrected" in e:
-            pixels = e["SQ_WAVES"] * float(e.get("pixels_per_wave", 64))
-            return (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / pixels, os.path.basename(files[-1])
-    return None, None
+        return None, "no profiles/r*_pmc.json"
+    for path in files:
+        data = json.load(open(path))
+        meta = data.get("_meta", {})
+        config = meta.get("config", {})
+        if not config or config.get("frame") != frame or config.get("spp") != spp:
+            continue
+        for name, entry in data.items():
+            if name.replace("rf::", "").replace(" ", "") == kernel.replace(" ", "") and entry.get("SQ_WAVES"):
+                return {"file": os.path.basename(path), "commit": meta.get("commit"), "config": config,
+                        "entry": entry}, None
+    return None, f"no committed PMC summary for {kernel} at frame {frame} / spp {spp}"
 
 
-def pmc_valu_summary():
-    """VALU-side figures of the render kernel from the same PMC summary (the kernel is bound by
-    vector-ALU issue, not by HBM): instructions per wave and per 64 pixels, lane utilisation, SIMD
-    cycles available per VALU instruction issued."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
-        return None
-    for name, e in json.load(open(files[-1])).items():
-        if "render_kernel" in name and e.get("valu_insts_per_wave"):
-            per_wave = float(e.get("pixels_per_wave", 64))
-            return {"insts_per_wave": e["valu_insts_per_wave"],
-                    "insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / per_wave,
-                    "lane_utilisation": e.get("valu_lane_utilisation"),
-                    "simd_cycles_per_inst": e.get("simd_cycles_per_valu_inst"),
-                    "source": os.path.basename(files[-1])}
-    return None
+def roofline_from_profile(profile, pixels_per_launch):
+    e = profile["entry"]
+    pixels = e["SQ_WAVES"] * float(e.get("pixels_per_wave", 64))
+    traffic = None
+    if "hbm_read_bytes_corrected" in e and "hbm_write_bytes" in e:
+        traffic = (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / pixels * pixels_per_launch
+    valu = None
+    if e.get("valu_insts_per_cycle_per_simd") is not None:
+        valu = {
+            "bound": "valu-issue",
+            "achieved": e["valu_insts_per_cycle_per_simd"],
+            "peak": VALU_ISSUE_PEAK,
+            "unit": "wave64 VALU instructions / cycle / SIMD",
+            "frac": e["valu_insts_per_cycle_per_simd"] / VALU_ISSUE_PEAK,
+            "formula": "SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), peak = 1 instruction per 2 cycles",
+            "lane_utilisation": e.get("valu_lane_utilisation"),
+            "lane_ops_frac_of_peak": (e["valu_insts_per_cycle_per_simd"] / VALU_ISSUE_PEAK
+                                      * e.get("valu_lane_utilisation", 1.0)),
+            "barrier_wait_share": e.get("wait_share"),        # SQ_WAIT_ANY / SQ_WAVE_CYCLES
+            "inst_wait_share": e.get("inst_wait_share"),      # SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+            "salu_per_valu": e.get("salu_per_valu"),          # SQ_INSTS_SALU / SQ_INSTS_VALU
+            "valu_insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / float(e.get("pixels_per_wave", 64)),
+            "from_committed_profile": True,
+            "profile": {k: profile[k] for k in ("file", "commit", "config")},
+        }
+    return traffic, valu
 
 
 def shard_plan(rank, envs_per_gpu, frame):
@@ -135,66 +214,111 @@ def shard_plan(rank, envs_per_gpu, frame):
     return {"first_env": rank * envs_per_gpu, "first_state_index": rank * envs_per_gpu * frame * frame}
 
 
-def cpu_baseline(frame, spp, n_envs):
-    """The CPU oracle (a port: the reference's numba-CUDASIM path is not runnable here)
-    timed on this host's cores on a bounded sample of the same workload (~12 s of work).
-    Seeding is untimed; to keep it short the sample's RNG states are the first env's
-    numba-seeded states tiled over the sampled envs (same arithmetic per pixel)."""
-    from oracle import oracle as orc
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only)
+# ---------------------------------------------------------------------------------------------
+def host_cores():
+    """Every core this process may run on (the GPU box gives one GPU's share of the host)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_pass(orc, frame, spp, n, cores, states, rng):
+    """One render + focus pass of the C oracle over n synthetic environments; seconds."""
     from reinfocus_amd.graphics import camera, world
 
-    cores = min(os.cpu_count() or 1, 16)
+    targets = rng.uniform(5, 10, n).astype(np.float32)
+    focus = rng.uniform(5, 10, n).astype(np.float32)
+    cams = camera.FastCameras()
+    cams.update(focus)
+    worlds = world.FastWorlds()
+    worlds.update(targets)
+    dyn, origin, u, v, lens = cams.device_data()
+    t0 = time.perf_counter()
+    frames = orc.render(dyn, worlds.device_data(), frame, frame, spp, states,
+                        cs=orc.cam_static(origin, u, v, float(lens)), n_threads=cores)
+    orc.focus_values(frames, 15, cores)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(frame, spp, n_envs, device):
+    """The CPU oracle (a port: the reference's numba-CUDASIM path cannot run here) timed on ALL of
+    this host's cores on a bounded sample of the same workload (~12 s of work), every environment
+    with its own numba-seeded RNG states.  Seeding is untimed: the sample's states come from
+    rf_seed (bit-identical to numba's sequential seeding, tests/test_gpu_parity.py), which
+    takes milliseconds where the sequential definition takes ~0.5 s per million states.
+    BASELINE.json configs[0] and configs[1] are small enough to be timed in full."""
+    from oracle import oracle as orc
+    from reinfocus_amd import _native
+
+    cores = host_cores()
     rng = np.random.Generator(np.random.PCG64DXSM(0))
-    one_env = orc.seed_states(frame * frame, 0)
+    ctx = _native.Context(device)
 
-    def run(n):
-        targets = rng.uniform(5, 10, n).astype(np.float32)
-        focus = rng.uniform(5, 10, n).astype(np.float32)
-        cams = camera.FastCameras()
-        cams.update(focus)
-        worlds = world.FastWorlds()
-        worlds.update(targets)
-        dyn, origin, u, v, lens = cams.device_data()
-        states = np.ascontiguousarray(np.tile(one_env, (n, 1)))
-        t0 = time.perf_counter()
-        frames = orc.render(dyn, worlds.device_data(), frame, frame, spp, states,
-                            cs=orc.cam_static(origin, u, v, float(lens)), n_threads=cores)
-        orc.focus_values(frames, 15, cores)
-        return time.perf_counter() - t0
+    def seeded(n, h):
+        ctx.seed(n * h * h, 0, 0)
+        return ctx.get_states()
 
-    if n_envs <= 0:
-        dt = run(cores)  # calibration: one env per thread
-        n_envs = int(max(cores, min(4096, round(12.0 * cores / max(dt, 1e-3)))))
-    dt = run(n_envs)
-    return {"value": n_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_envs} envs x {frame}x{frame} x {spp} spp, one render+focus pass of the C oracle "
-                      f"(OpenMP, {cores} threads), {dt:.1f} s"}
+    try:
+        if n_envs <= 0:
+            dt = cpu_pass(orc, frame, spp, cores, cores, seeded(cores, frame), rng)  # calibration: one env per thread
+            n_envs = int(max(cores, min(4096, round(12.0 * cores / max(dt, 1e-3)))))
+        dt = cpu_pass(orc, frame, spp, n_envs, cores, seeded(n_envs, frame), rng)
+        others = []
+        for label, n, h, s in (("configs[0]: 1 env x 64x64 x 1 spp", 1, 64, 1),
+                               ("configs[1]: 256 envs x 128x128 x 4 spp", 256, 128, 4)):
+            t = min(cpu_pass(orc, h, s, n, cores, seeded(n, h), rng) for _ in range(3))
+            others.append({"workload": label + " (full)", "value": n / t, "unit": "env-steps/s", "seconds": t})
+    finally:
+        ctx.close()
+    return {"value": n_envs / dt, "unit": "env-steps/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{n_envs} envs x {frame}x{frame} x {spp} spp, each with its own seeded RNG states: one "
+                      f"render + focus pass of the C oracle (OpenMP, {cores} threads = every core of this "
+                      f"process's affinity mask), {dt:.1f} s",
+            "other_configs": others}
 
 
+# ---------------------------------------------------------------------------------------------
 def main(argv=None):
-    args = parse_args(argv)
-    ranks = Ranks(args.gpus)
+    raw = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(raw)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.sharded_env:
+        raise SystemExit(launch_ranks(args.gpus, raw))
+
+    ranks = Ranks(args.gpus, single_process=args.sharded_env)
+    if args.plumbing_test and os.environ.get("REINFOCUS_BENCH_FAIL_RANK") == str(ranks.rank):
+        sys.exit(3)  # test hook: a rank that dies must fail the whole launch
     n_local, frame, spp = args.envs_per_gpu, args.frame, args.spp
     plan = shard_plan(ranks.rank, n_local, frame)
+    n_here = n_local * (args.gpus if args.sharded_env else 1)  # environments this process steps
 
     env = None
+    ctx = None
     if not args.plumbing_test:
         # the HIP library is loaded before anything else can pull a second HIP runtime in
         from reinfocus_amd import _native
         from reinfocus_amd.environments import harness
 
-        if _native.device_count() < 1:
-            raise SystemExit("bench.py needs a GPU: reinfocus_amd has no CPU fallback")
+        if _native.device_count() < (args.gpus if args.sharded_env else 1):
+            raise SystemExit("bench.py needs a GPU per rank: reinfocus_amd has no CPU fallback")
         device = int(os.environ.get("REINFOCUS_BENCH_DEVICE", ranks.local_rank))
-        env_cls = harness.DeviceVectorDiscreteSteps if args.env == "device" else harness.VectorDiscreteSteps
-        env = env_cls(num_envs=n_local, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank,
-                      device=device, first_state_index=plan["first_state_index"])
-        ctx = env._ctx if args.env == "device" else env._renderer._ctx
+        common = dict(num_envs=n_here, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank)
+        if args.sharded_env:
+            env = harness.ShardedVectorDiscreteSteps(devices=list(range(args.gpus)), **common)
+            contexts = [shard.ctx for shard in env._shards]
+        else:
+            env_cls = harness.DeviceVectorDiscreteSteps if args.env == "device" else harness.VectorDiscreteSteps
+            env = env_cls(device=device, first_state_index=plan["first_state_index"], **common)
+            contexts = [env._ctx if args.env == "device" else env._renderer._ctx]
+        ctx = contexts[0]
         env.reset()
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
     def one_step():
-        actions = action_rng.integers(0, 13, n_local)
+        actions = action_rng.integers(0, 13, n_here)
         if env is None:
             time.sleep(0.002)
             return 0
@@ -205,23 +329,26 @@ def main(argv=None):
         one_step()
 
     if env is not None:
-        if not args.no_kernel_timing:
-            ctx.timing(True)
-        ctx.synchronize()
+        for c in contexts:
+            if not args.no_kernel_timing:
+                c.timing(True)
+            c.synchronize()
     ranks.barrier()
     t0 = time.perf_counter()
     resets = 0
     for _ in range(args.steps):
         resets += one_step()
     if env is not None:
-        ctx.synchronize()
+        for c in contexts:
+            c.synchronize()
     elapsed_local = time.perf_counter() - t0
     ranks.barrier()
     elapsed = ranks.reduce(elapsed_local, "MAX")
     total_resets = ranks.reduce(resets, "SUM")
 
     timing = ctx.timing_read() if env is not None and not args.no_kernel_timing else None
-    total_envs = n_local * ranks.world
+    n_gpus = args.gpus if args.sharded_env else ranks.world
+    total_envs = n_local * n_gpus
     value = total_envs * args.steps / elapsed if env is not None else None
 
     out = None
@@ -230,7 +357,7 @@ def main(argv=None):
             "metric": "vectorised env steps/sec @ 4096 envs 256x256x16spp; 1->8 GPU scaling",
             "value": value,
             "unit": "env-steps/s",
-            "n_gpus": ranks.world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -247,45 +374,53 @@ def main(argv=None):
                 "frame": frame,
                 "spp": spp,
                 "auto_resets_per_step": total_resets / max(args.steps, 1),
-                "sharding": "independent env ranges per rank, no data-path collective",
+                "sharding": ("one process, one rf_ctx + host thread per GPU (ShardedVectorDiscreteSteps)"
+                             if args.sharded_env else "one process per GPU, independent env ranges") +
+                            ", no data-path collective",
                 "env_glue": "device-resident (rf_env_step)" if args.env == "device" else "host numpy (harness)",
             },
         }
         if timing is not None:
-            # full renders + the partial auto-reset renders of rank 0
-            pixels = (args.steps * n_local + resets) * frame * frame
+            # full renders + the partial auto-reset renders of rank 0 (of shard 0 with --sharded-env)
+            resets_here = resets if not args.sharded_env else resets / n_gpus
+            pixels = (args.steps * n_local + resets_here) * frame * frame
             render_s = timing["render_ms"] / 1000.0
             focus_s = timing["focus_ms"] / 1000.0
             achieved = RENDER_BYTES_PER_PIXEL * pixels / render_s / 1e9
             launches = max(timing["render_launches"], 1)
-            pmc_bpp, pmc_file = pmc_bytes_per_pixel()
+            kernel = ctx.render_kernel_name()
+            profile, why_not = committed_profile(kernel, frame, spp)
+            traffic, valu = roofline_from_profile(profile, pixels / launches) if profile else (None, None)
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "render_kernel_coop2<POW2>",
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None if pmc_bpp is None else pmc_bpp * pixels / launches,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                "traffic_source": pmc_file,
+                "measured_in_this_run": ["achieved", "frac", "avg_launch_ms", "launches", "samples_per_s"],
                 "algorithmic_bytes_per_launch": RENDER_BYTES_PER_PIXEL * pixels / launches,
                 "algorithmic_bytes_per_pixel": RENDER_BYTES_PER_PIXEL,
-                "avg_launch_ms": timing["render_ms"] / max(timing["render_launches"], 1),
+                "avg_launch_ms": timing["render_ms"] / launches,
                 "launches": timing["render_launches"],
                 "samples_per_s": pixels * spp / render_s,
-                "valu": pmc_valu_summary(),
-                "note": "VALU-bound by construction (64-bit xoroshiro128+ draws and rejection loops fixed "
-                        "by parity): see DESIGN.md section Roofline",
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_from_committed_profile": traffic is not None,
+                "traffic_profile": ({k: profile[k] for k in ("file", "commit", "config")} if profile
+                                    else {"unavailable": why_not}),
+                "note": "HBM is the nominated roof; the kernel is bound by VALU issue (64-bit xoroshiro128+ "
+                        "draws and rejection loops fixed by parity): see roofline_valu and DESIGN.md",
             }
+            out["roofline_valu"] = valu if valu is not None else {"unavailable": why_not, "from_committed_profile": True}
             out["focus_kernel"] = {
                 "achieved_GBps": FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9,
                 "avg_launch_ms": timing["focus_ms"] / max(timing["focus_launches"], 1),
                 "launches": timing["focus_launches"],
             }
             out["kernel_time_frac_of_wall"] = (render_s + focus_s) / elapsed_local
-        if env is not None and not args.no_cpu_baseline and ranks.world == 1:
-            out["cpu_baseline"] = cpu_baseline(frame, spp, args.cpu_baseline_envs)
+        if env is not None and not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(frame, spp, args.cpu_baseline_envs, ctx.device)
     if env is not None:
         env.close()
     ranks.close()

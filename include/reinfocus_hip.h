@@ -109,6 +109,11 @@ int rf_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, double *host_var);
  * per step (environments/state_observer.py:377-381) without the frame D2H. */
 int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *host_var);
 
+/* Name of the render kernel (template instance included) the ctx's last render launch used,
+ * e.g. "render_kernel_coop2<true, 1, 4, 32>"; "none" before the first render.  The string is static.
+ * No reference counterpart (bench.py reports it next to the roofline figures). */
+const char *rf_render_kernel_name(rf_ctx *ctx);
+
 /* Blocks until everything enqueued on the ctx's stream has finished. */
 int rf_synchronize(rf_ctx *ctx);
 
@@ -180,6 +185,34 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs);
  * false for this environment). */
 int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool, float *host_obs,
                 double *host_rewards, uint8_t *host_truncated, int *host_n_reset);
+
+/* The same step in two halves, for an environment sharded over several contexts / GPUs
+ * (harness.ShardedVectorDiscreteSteps): which rows of the initializer's pool a shard takes depends
+ * on how many environments ended in the shards before it (vector_environment.py:138-142 draws
+ * done.sum() states for the done environments in index order).
+ *   rf_env_step_begin   transform, enders, full render + focus, observations, rewards, flags
+ *                       (vector_environment.py:124-135); *host_n_reset = k environments ended
+ *   rf_env_step_end     those k environments take host_pool float32[k][2] in index order and are
+ *                       rendered and scored again (vector_environment.py:137-151); observations
+ *                       float32[n][4] of all environments.  host_pool may be NULL when k == 0.
+ * rf_env_step == begin + end with the pool's first k rows. */
+int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rewards, uint8_t *host_truncated,
+                      int *host_n_reset);
+int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs);
+
+/* Renders the scene set the environment uploaded last -- all n environments after a step in which
+ * none ended, otherwise only the k that were reset, exactly what the reference's shared
+ * FastRenderer holds at that point -- at frame_height x frame_height with spp samples, advancing
+ * RNG states [0, len * frame_height^2); host_out uint8[len][frame_height][frame_height][3] may be
+ * NULL (frames stay in the ctx's buffer).  rf_env_scene_len returns len.
+ * Replaces: HistoryVisualizer.visualize's renderer.render(600)
+ * (environments/episode_visualizer.py:197) on the renderer FocusObserver shares with it. */
+int rf_env_scene_len(rf_ctx *ctx, int *n_envs);
+int rf_env_render(rf_ctx *ctx, int frame_height, int spp, uint8_t *host_out);
+
+/* TimeLimitEnder._steps and DivergingEnder._diverging_steps, int32[n] each (what the visualiser
+ * prints: episode_ender.py:191-207, :646-656). */
+int rf_env_get_counters(rf_ctx *ctx, int32_t *host_steps, int32_t *host_diverging);
 
 /* Current states float32[n][2] (tests / checkpoint). */
 int rf_env_get_states(rf_ctx *ctx, float *host_states);

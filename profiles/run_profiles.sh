@@ -1,18 +1,25 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round: kernel-trace stats of the default bench
-# command, then PMC passes (counters only; never combined with tracing domains).
-# usage (on the GPU box, from the repo root):  bash profiles/run_profiles.sh r01
+# Collects the rocprofv3 evidence for one configuration: kernel-trace stats of the bench command,
+# then PMC passes (counters only; never combined with tracing domains).
+# usage (on the GPU box, from the repo root):
+#   bash profiles/run_profiles.sh r02                        # headline config (bench.py defaults)
+#   bash profiles/run_profiles.sh r02_c1 "--envs-per-gpu 256 --frame 128 --spp 4" 200
+#   (tag, extra bench.py arguments, steps of the traced run)
+# then, back in the container:  python profiles/summarize.py <tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+ARGS=${2:-}
+TRACE_STEPS=${3:-50}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# kernel trace of the DEFAULT bench command (50 + 5 steps) so that the average launch duration is
+# kernel trace of the bench command at its default length so that the average launch duration is
 # the one bench.py's HIP events report; the PMC passes replay every kernel and use a short run
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $ARGS"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps $TRACE_STEPS --no-cpu-baseline $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
+grep "^{" $OUT/trace.log > $OUT/bench.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY \
     --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
 echo "pmc_sq rc=$?"

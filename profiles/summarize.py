@@ -13,6 +13,18 @@ import shutil
 import sys
 
 
+def git_commit(root):
+    import subprocess
+
+    try:
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        dirty = subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "reinfocus_amd", "bench.py"],
+                                        text=True).strip()
+        return head + ("+uncommitted" if dirty else "")
+    except Exception:  # not a checkout
+        return None
+
+
 def main(tag):
     root = os.path.dirname(os.path.abspath(__file__))
     src = os.path.join(root, "..", "gpurun_out", "prof_" + tag)
@@ -52,11 +64,34 @@ def main(tag):
             e["simd_cycles_per_valu_inst"] = e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / e["SQ_INSTS_VALU"]
         if "SQ_THREAD_CYCLES_VALU" in e and e.get("SQ_ACTIVE_INST_VALU"):
             e["valu_lane_utilisation"] = e["SQ_THREAD_CYCLES_VALU"] / (e["SQ_ACTIVE_INST_VALU"] * 64)
+        # VALU issue rate against its peak of one wave64 instruction per 2 cycles per SIMD
+        if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_INSTS_VALU"):
+            e["valu_insts_per_cycle_per_simd"] = e["SQ_INSTS_VALU"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            e["valu_issue_frac_of_peak"] = e["valu_insts_per_cycle_per_simd"] / 0.5
+        if e.get("SQ_WAVE_CYCLES"):
+            if "SQ_WAIT_ANY" in e:
+                e["wait_share"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+            if "SQ_WAIT_INST_ANY" in e:
+                e["inst_wait_share"] = e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]
+        if e.get("SQ_INSTS_VALU") and "SQ_INSTS_SALU" in e:
+            e["salu_per_valu"] = e["SQ_INSTS_SALU"] / e["SQ_INSTS_VALU"]
         out[k] = e
+    # what was profiled: the bench line of the PMC passes' command (run_profiles.sh writes it) and the commit
+    meta = {"commit": git_commit(os.path.join(root, "..")), "config": None}
+    bench_line = os.path.join(src, "bench.json")
+    if os.path.exists(bench_line):
+        for line in open(bench_line):
+            if line.startswith("{"):
+                b = json.loads(line)
+                meta["config"] = {"envs": b["config"]["envs_per_gpu"], "frame": b["config"]["frame"],
+                                  "spp": b["config"]["spp"], "kernel": b.get("roofline", {}).get("kernel")}
+                shutil.copy(bench_line, os.path.join(root, tag + "_bench.json"))
+    out["_meta"] = meta
     with open(os.path.join(root, tag + "_pmc.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(open(os.path.join(root, tag + "_kernel_stats.csv")).read())
-    print(json.dumps({k: {m: v[m] for m in v if m.startswith(("hbm", "valu", "launches"))} for k, v in out.items()}, indent=1))
+    print(json.dumps({k: {m: v[m] for m in v if m.startswith(("hbm", "valu", "launches", "wait", "inst_wait", "salu", "commit", "config"))}
+                      for k, v in out.items()}, indent=1))
 
 
 if __name__ == "__main__":

@@ -48,7 +48,13 @@ SYMBOLS = (
     "rf_env_configure",
     "rf_env_reset",
     "rf_env_step",
+    "rf_env_step_begin",
+    "rf_env_step_end",
     "rf_env_get_states",
+    "rf_env_scene_len",
+    "rf_env_render",
+    "rf_env_get_counters",
+    "rf_render_kernel_name",
 )
 
 
@@ -125,7 +131,14 @@ def load():
     lib.rf_env_configure.argtypes = [vp, ctypes.POINTER(EnvConfig)]
     lib.rf_env_reset.argtypes = [vp, vp, vp]
     lib.rf_env_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
+    lib.rf_env_step_begin.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
+    lib.rf_env_step_end.argtypes = [vp, vp, vp]
     lib.rf_env_get_states.argtypes = [vp, vp]
+    lib.rf_env_scene_len.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.rf_env_render.argtypes = [vp, i32, i32, vp]
+    lib.rf_env_get_counters.argtypes = [vp, vp, vp]
+    lib.rf_render_kernel_name.restype = ctypes.c_char_p
+    lib.rf_render_kernel_name.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -276,6 +289,44 @@ class Context:
         _check(self._lib.rf_env_step(self._h, _ptr(actions), _ptr(pool), _ptr(obs), _ptr(rewards), _ptr(truncated),
                                      ctypes.byref(k)))
         return obs, rewards, truncated.astype(bool), k.value
+
+    def env_step_begin(self, actions):
+        """First half of a two-phase step: (rewards, truncated, number of environments that ended)."""
+        n = self._env_n
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(n)
+        rewards = np.empty(n, dtype=np.float64)
+        truncated = np.empty(n, dtype=np.uint8)
+        k = ctypes.c_int(0)
+        _check(self._lib.rf_env_step_begin(self._h, _ptr(actions), _ptr(rewards), _ptr(truncated), ctypes.byref(k)))
+        return rewards, truncated.astype(bool), k.value
+
+    def env_step_end(self, pool_rows):
+        """Second half: the environments that ended take pool_rows float32[k, 2]; observations."""
+        n = self._env_n
+        pool_rows = np.ascontiguousarray(pool_rows, dtype=np.float32).reshape(-1, 2)
+        obs = np.empty((n, 4), dtype=np.float32)
+        _check(self._lib.rf_env_step_end(self._h, _ptr(pool_rows) if len(pool_rows) else None, _ptr(obs)))
+        return obs
+
+    def env_scene_len(self):
+        n = ctypes.c_int(0)
+        _check(self._lib.rf_env_scene_len(self._h, ctypes.byref(n)))
+        return n.value
+
+    def env_render(self, frame_height, spp):
+        """uint8[len, h, h, 3] of the scene set the environment uploaded last."""
+        out = np.empty((self.env_scene_len(), frame_height, frame_height, 3), dtype=np.uint8)
+        _check(self._lib.rf_env_render(self._h, int(frame_height), int(spp), _ptr(out)))
+        return out
+
+    def env_counters(self):
+        steps = np.empty(self._env_n, dtype=np.int32)
+        diverging = np.empty(self._env_n, dtype=np.int32)
+        _check(self._lib.rf_env_get_counters(self._h, _ptr(steps), _ptr(diverging)))
+        return steps, diverging
+
+    def render_kernel_name(self):
+        return self._lib.rf_render_kernel_name(self._h).decode()
 
     def env_states(self):
         out = np.empty((self._env_n, 2), dtype=np.float32)

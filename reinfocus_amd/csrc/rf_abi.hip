@@ -106,6 +106,13 @@ struct rf_ctx {
     size_t h_stage_bytes = 0;
     uint64_t env_steps = 0;
     bool env_axis = false;
+    bool env_last_partial = false; // that set is the compacted one of an auto-reset (cam_dyn2 / rect2)
+    int env_scene_len = 0; // environments of the scene set uploaded last: n after a full render, k after a partial one
+    int env_pending = -1; // >= 0: rf_env_step_begin ran and that many environments wait for rf_env_step_end
+    bool env_graph_fail_once = false; // REINFOCUS_ENV_GRAPH_FAIL=1 (tests): the first instantiation "fails"
+    const char *render_kernel = "none"; // the render kernel the last launch used (rf_render_kernel_name)
+    void *general_scratch = nullptr;    // scene arrays of rf_render_general (grown on demand)
+    size_t general_scratch_bytes = 0;
 
     bool timing = false;
     std::vector<EventPair> ev_render, ev_focus;
@@ -309,6 +316,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->tile_layout = (v[0] >= '0' && v[0] <= '5') ? v[0] - '0' : -1;
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
+        ctx->env_graph_fail_once = v[0] == '1';
 
     std::vector<rf::Mat128> tables;
     if (!rf::h_build_jump_tables(rf::kSeedMats, tables)) {
@@ -356,6 +365,7 @@ int rf_destroy(rf_ctx *ctx)
     if (ctx->env_graph) (void)hipGraphExecDestroy(ctx->env_graph);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->env_block) (void)hipFree(ctx->env_block);
+    if (ctx->general_scratch) (void)hipFree(ctx->general_scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RF_OK;
@@ -525,15 +535,18 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
                               ne);
             const bool lens32 = a.cs.lens_f32 != 0;
             if (axis && ctx->coop && ctx->two_sets) {
+#define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
+    hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW>), tiles2, block, 0, ctx->stream, b);          \
+    ctx->render_kernel = "render_kernel_coop2<" #P ", " #L ", " #WX ", " #WW ">"
 #define RF_LAUNCH2(P, L)                                                                                   \
     do {                                                                                                   \
         switch (layout) {                                                                                  \
-        case 0: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 32>), tiles2, block, 0, ctx->stream, b); break; \
-        case 1: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 32>), tiles2, block, 0, ctx->stream, b); break; \
-        case 2: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 64>), tiles2, block, 0, ctx->stream, b); break; \
-        case 3: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 64>), tiles2, block, 0, ctx->stream, b); break; \
-        case 4: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 4, 16>), tiles2, block, 0, ctx->stream, b); break; \
-        default: hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, 2, 16>), tiles2, block, 0, ctx->stream, b); break; \
+        case 0: RF_LAUNCH2_ONE(P, L, 4, 32); break;                                                        \
+        case 1: RF_LAUNCH2_ONE(P, L, 2, 32); break;                                                        \
+        case 2: RF_LAUNCH2_ONE(P, L, 4, 64); break;                                                        \
+        case 3: RF_LAUNCH2_ONE(P, L, 2, 64); break;                                                        \
+        case 4: RF_LAUNCH2_ONE(P, L, 4, 16); break;                                                        \
+        default: RF_LAUNCH2_ONE(P, L, 2, 16); break;                                                       \
         }                                                                                                  \
     } while (0)
                 if (pow2 && lens32)
@@ -544,20 +557,28 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
                     RF_LAUNCH2(false, 1);
                 else
                     RF_LAUNCH2(false, 0);
+#undef RF_LAUNCH2_ONE
 #undef RF_LAUNCH2
             }
-            else if (axis && ctx->coop && pow2)
+            else if (axis && ctx->coop && pow2) {
                 hipLaunchKernelGGL((rf::render_kernel_coop<true>), tiles, block, 0, ctx->stream, b);
-            else if (axis && ctx->coop)
+                ctx->render_kernel = "render_kernel_coop<true>";
+            } else if (axis && ctx->coop) {
                 hipLaunchKernelGGL((rf::render_kernel_coop<false>), tiles, block, 0, ctx->stream, b);
-            else if (axis && pow2)
+                ctx->render_kernel = "render_kernel_coop<false>";
+            } else if (axis && pow2) {
                 hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
-            else if (axis)
+                ctx->render_kernel = "render_kernel<true, true>";
+            } else if (axis) {
                 hipLaunchKernelGGL((rf::render_kernel<true, false>), grid, block, 0, ctx->stream, b);
-            else if (pow2)
+                ctx->render_kernel = "render_kernel<true, false>";
+            } else if (pow2) {
                 hipLaunchKernelGGL((rf::render_kernel<false, true>), grid, block, 0, ctx->stream, b);
-            else
+                ctx->render_kernel = "render_kernel<false, true>";
+            } else {
                 hipLaunchKernelGGL((rf::render_kernel<false, false>), grid, block, 0, ctx->stream, b);
+                ctx->render_kernel = "render_kernel<false, false>";
+            }
         }
     }
     RF_HIP(hipGetLastError());
@@ -692,6 +713,8 @@ int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *ho
     return rf_focus(ctx, n, h, w, gray_mode, host_var);
 }
 
+const char *rf_render_kernel_name(rf_ctx *ctx) { return ctx ? ctx->render_kernel : "none"; }
+
 int rf_synchronize(rf_ctx *ctx)
 {
     RF_REQUIRE(ctx != nullptr, "rf_synchronize: ctx is NULL");
@@ -759,8 +782,16 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                  b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t);
     const size_t o_par = (b_cam + 255) & ~(size_t)255, o_typ = o_par + ((b_par + 255) & ~(size_t)255),
                  o_siz = o_typ + ((b_typ + 255) & ~(size_t)255), total = o_siz + b_siz;
-    char *scratch = nullptr;
-    RF_HIP(hipMalloc((void **)&scratch, total));
+    if (total > ctx->general_scratch_bytes) { // grown on demand, owned by the ctx
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->general_scratch)
+            RF_HIP(hipFree(ctx->general_scratch));
+        ctx->general_scratch = nullptr;
+        ctx->general_scratch_bytes = 0;
+        RF_HIP(hipMalloc(&ctx->general_scratch, total));
+        ctx->general_scratch_bytes = total;
+    }
+    char *const scratch = (char *)ctx->general_scratch;
     hipError_t he = hipMemcpyAsync(scratch, cameras, b_cam, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_typ, types, b_typ, hipMemcpyHostToDevice, ctx->stream);
@@ -794,12 +825,12 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             b.sizes = a.sizes + e0;
             b.n = ne;
             hipLaunchKernelGGL(rf::render_general_kernel, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
+            ctx->render_kernel = "render_general_kernel";
             he = hipGetLastError();
         }
     }
     if (he == hipSuccess)
         he = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(scratch);
     if (he != hipSuccess) {
         set_err("rf_render_general: %s", hipGetErrorString(he));
         return RF_ERR_HIP;
@@ -902,6 +933,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
                     !signbit(cfg->cam_u[1]) && !signbit(cfg->cam_u[2]) && !signbit(cfg->cam_v[0]) &&
                     !signbit(cfg->cam_v[2]) && cfg->half_width > 0.0 && cfg->half_height > 0.0;
     ctx->scene_n = 0; // the env owns the scene arrays from now on
+    ctx->env_pending = -1;
     ctx->env_ready = true;
     return RF_OK;
 }
@@ -911,6 +943,7 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     RF_REQUIRE(ctx != nullptr && host_states != nullptr && host_obs != nullptr, "rf_env_reset: NULL argument");
     RF_REQUIRE(ctx->env_ready, "rf_env_reset: rf_env_configure first");
     RF_HIP(hipSetDevice(ctx->device));
+    ctx->env_pending = -1;
     const rf_env_config &h = ctx->env_host;
     const int n = h.n, fh = h.frame_height;
     RF_HIP(hipMemcpyAsync(ctx->env.state, host_states, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -926,6 +959,8 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     RF_HIP(hipGetLastError());
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_scene_len = n;
+    ctx->env_last_partial = false;
     return RF_OK;
 }
 
@@ -960,7 +995,7 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
     hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const double *)ctx->d_var, 0);
     hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const float *)ctx->d_pool);
+                       (const float *)ctx->d_pool, rf::kEnvResetBoth);
     rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
     if (rc == RF_OK)
         rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
@@ -975,6 +1010,59 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
     return RF_OK;
 }
 
+// First half of a step: transform, enders, full render + focus, observations, rewards, flags, and
+// the ranking of the environments that ended (vector_environment.py:124-135).  Synchronises once:
+// *k, rewards and truncated are final on return; the observations of the environments that did not
+// end are final on the device.
+int env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rewards, uint8_t *host_truncated, int *k)
+{
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const int *)ctx->d_actions);
+    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+    if (rc != RF_OK)
+        return rc;
+    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const double *)ctx->d_var, 0);
+    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const float *)nullptr, rf::kEnvResetRank);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
+// Second half: the k environments that ended take host_pool's rows 0..k-1 in index order and are
+// rendered and scored again (vector_environment.py:137-151), with the launch sized by k.
+int env_step_end(rf_ctx *ctx, const float *host_pool, int k, float *host_obs)
+{
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    if (k > 0) {
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool, rf::kEnvResetApply);
+        int rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
+                           ctx->env, (const double *)ctx->d_var);
+        RF_HIP(hipGetLastError());
+    }
+    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    return RF_OK;
+}
+
 } // namespace
 
 int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool, float *host_obs,
@@ -983,9 +1071,10 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     RF_REQUIRE(ctx != nullptr && host_actions && host_pool && host_obs && host_rewards && host_truncated,
                "rf_env_step: NULL argument");
     RF_REQUIRE(ctx->env_ready, "rf_env_step: rf_env_configure first");
+    RF_REQUIRE(ctx->env_pending < 0, "rf_env_step: a two-phase step is open (rf_env_step_end first)");
     RF_HIP(hipSetDevice(ctx->device));
     const rf_env_config &h = ctx->env_host;
-    const int n = h.n, fh = h.frame_height;
+    const int n = h.n;
     for (int i = 0; i < n; ++i)
         RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions, "rf_env_step: action %d of env %d out of range",
                    host_actions[i], i);
@@ -1029,7 +1118,10 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
                                           (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
                     he = hipStreamEndCapture(ctx->stream, &captured);
-                    if (he == hipSuccess && rc == RF_OK)
+                    if (he == hipSuccess && rc == RF_OK && ctx->env_graph_fail_once) {
+                        ctx->env_graph_fail_once = false; // test hook: behave as if instantiation had failed
+                        he = hipErrorUnknown;
+                    } else if (he == hipSuccess && rc == RF_OK)
                         he = hipGraphInstantiate(&ctx->env_graph, captured, nullptr, nullptr, 0);
                     if (captured)
                         (void)hipGraphDestroy(captured);
@@ -1044,6 +1136,8 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     RF_HIP(hipGetLastError());
                     RF_HIP(hipStreamSynchronize(ctx->stream));
                     ctx->env_steps += 1;
+                    ctx->env_scene_len = k > 0 ? k : n;
+                    ctx->env_last_partial = k > 0;
                     if (host_n_reset)
                         *host_n_reset = k;
                     return RF_OK;
@@ -1059,42 +1153,100 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             k = *(const int *)(st + o_cnt);
         }
     } else {
-        RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-        const dim3 grid((n + 255) / 256), block(256);
-        hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const int *)ctx->d_actions);
-        int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+        // the step's flags and rewards are final after the first half; the count sizes the partial render
+        int rc = env_step_begin(ctx, host_actions, host_rewards, host_truncated, &k);
         if (rc == RF_OK)
-            rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+            rc = env_step_end(ctx, host_pool, k, host_obs);
         if (rc != RF_OK)
             return rc;
-        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const double *)ctx->d_var, 0);
-        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const float *)ctx->d_pool);
-        RF_HIP(hipGetLastError());
-        // the step's flags and rewards are final here; the count sizes the partial render
-        RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipStreamSynchronize(ctx->stream));
-        if (k > 0) {
-            rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
-            if (rc == RF_OK)
-                rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
-            if (rc != RF_OK)
-                return rc;
-            hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), block, 0, ctx->stream, ctx->env_cfg,
-                               ctx->env, (const double *)ctx->d_var);
-            RF_HIP(hipGetLastError());
-        }
-        RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        RF_HIP(hipStreamSynchronize(ctx->stream));
     }
     ctx->env_steps += 1;
+    ctx->env_scene_len = k > 0 ? k : n;
+    ctx->env_last_partial = k > 0;
     if (host_n_reset)
         *host_n_reset = k;
+    return RF_OK;
+}
+
+int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rewards, uint8_t *host_truncated,
+                      int *host_n_reset)
+{
+    RF_REQUIRE(ctx != nullptr && host_actions && host_rewards && host_truncated && host_n_reset,
+               "rf_env_step_begin: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_step_begin: rf_env_configure first");
+    RF_REQUIRE(ctx->env_pending < 0, "rf_env_step_begin: the previous step was not finished (rf_env_step_end)");
+    RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
+    const rf_env_config &h = ctx->env_host;
+    for (int i = 0; i < h.n; ++i)
+        RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions,
+                   "rf_env_step_begin: action %d of env %d out of range", host_actions[i], i);
+    int k = 0;
+    int rc = env_step_begin(ctx, host_actions, host_rewards, host_truncated, &k);
+    if (rc != RF_OK)
+        return rc;
+    ctx->env_pending = k;
+    *host_n_reset = k;
+    return RF_OK;
+}
+
+int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs)
+{
+    RF_REQUIRE(ctx != nullptr && host_obs != nullptr, "rf_env_step_end: NULL argument");
+    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0, "rf_env_step_end: rf_env_step_begin first");
+    RF_REQUIRE(ctx->env_pending == 0 || host_pool != nullptr, "rf_env_step_end: %d environments ended but host_pool is NULL",
+               ctx->env_pending);
+    RF_HIP(hipSetDevice(ctx->device));
+    const int k = ctx->env_pending;
+    ctx->env_pending = -1;
+    int rc = env_step_end(ctx, host_pool, k, host_obs);
+    if (rc == RF_OK) {
+        ctx->env_steps += 1;
+        ctx->env_scene_len = k > 0 ? k : ctx->env_host.n;
+        ctx->env_last_partial = k > 0;
+    }
+    return rc;
+}
+
+int rf_env_scene_len(rf_ctx *ctx, int *n_envs)
+{
+    RF_REQUIRE(ctx != nullptr && n_envs != nullptr, "rf_env_scene_len: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_scene_len: rf_env_configure first");
+    *n_envs = ctx->env_scene_len;
+    return RF_OK;
+}
+
+int rf_env_render(rf_ctx *ctx, int frame_height, int spp, uint8_t *host_out)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_env_render: ctx is NULL");
+    RF_REQUIRE(ctx->env_ready && ctx->env_scene_len > 0, "rf_env_render: rf_env_reset first");
+    RF_REQUIRE(ctx->env_pending < 0, "rf_env_render: a two-phase step is open (rf_env_step_end first)");
+    RF_REQUIRE(frame_height > 0 && spp > 0, "rf_env_render: frame_height, spp must be positive");
+    const int n = ctx->env_scene_len;
+    const uint64_t need = (uint64_t)n * frame_height * frame_height;
+    RF_REQUIRE(need <= ctx->n_states, "rf_env_render: %llu pixels but only %llu RNG states (rf_seed first)",
+               (unsigned long long)need, (unsigned long long)ctx->n_states);
+    RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
+    const bool partial = ctx->env_last_partial;
+    int rc = launch_render(ctx, n, frame_height, frame_height, spp, partial ? ctx->env.cam_dyn2 : ctx->env.cam_dyn,
+                           partial ? ctx->env.rect2 : ctx->env.rect, ctx->env_axis);
+    if (rc != RF_OK)
+        return rc;
+    if (host_out)
+        return rf_get_frames(ctx, 0, n, host_out);
+    return RF_OK;
+}
+
+int rf_env_get_counters(rf_ctx *ctx, int32_t *host_steps, int32_t *host_diverging)
+{
+    RF_REQUIRE(ctx != nullptr && host_steps != nullptr && host_diverging != nullptr, "rf_env_get_counters: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_get_counters: rf_env_configure first");
+    RF_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->env_host.n * 4;
+    RF_HIP(hipMemcpyAsync(host_steps, ctx->env.steps, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_diverging, ctx->env.diverging, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
     return RF_OK;
 }
 

@@ -149,10 +149,33 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
 // Ranks the done envs in index order (single block, running offset) and applies the
 // initializer's r-th candidate state to the r-th done env (vector_environment.py:138-142),
 // resets its enders, and packs the compacted scene of the partial render.
-__global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool)
+// mode kEnvResetBoth does all of it in one launch (rf_env_step); the two-phase step of a sharded
+// environment (rf_env_step_begin / rf_env_step_end) ranks first (kEnvResetRank: done_index,
+// done_count; no pool yet -- which rows of the initializer's pool a shard takes depends on how
+// many environments ended in the shards before it) and applies later (kEnvResetApply).
+constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2;
+
+__device__ __forceinline__ void env_apply_reset(const EnvConfig &c, const EnvState &s, const float *pool, int r, int e)
+{
+    const float target = pool[2 * r], focus = pool[2 * r + 1];
+    s.state[2 * e] = target;
+    s.state[2 * e + 1] = focus;
+    s.steps[e] = 0;
+    s.diverging[e] = 0;
+    s.last_diff[e] = fabsf(target - focus);
+    pack_scene(c, target, focus, s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+}
+
+__global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool, int mode)
 {
     __shared__ int wave_sum[16];
     __shared__ int running;
+    if (mode == kEnvResetApply) {
+        const int count = *s.done_count;
+        for (int r = (int)threadIdx.x; r < count; r += 1024)
+            env_apply_reset(c, s, pool, r, s.done_index[r]);
+        return;
+    }
     if (threadIdx.x == 0)
         running = 0;
     __syncthreads();
@@ -172,14 +195,9 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
         }
         if (d) {
             const int r = before + lane_rank;
-            const float target = pool[2 * r], focus = pool[2 * r + 1];
-            s.state[2 * e] = target;
-            s.state[2 * e + 1] = focus;
-            s.steps[e] = 0;
-            s.diverging[e] = 0;
-            s.last_diff[e] = fabsf(target - focus);
             s.done_index[r] = e;
-            pack_scene(c, target, focus, s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+            if (mode == kEnvResetBoth)
+                env_apply_reset(c, s, pool, r, e);
         }
         __syncthreads();
         if (threadIdx.x == 0)
@@ -189,8 +207,9 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
     if (threadIdx.x == 0)
         *s.done_count = running;
     // the auto-reset render is enqueued for all n slots: mark the ones it has to skip
-    for (int r = running + (int)threadIdx.x; r < c.n; r += 1024)
-        s.rect2[2 * r] = __builtin_bit_cast(float, kSkipEnvBits);
+    if (mode == kEnvResetBoth)
+        for (int r = running + (int)threadIdx.x; r < c.n; r += 1024)
+            s.rect2[2 * r] = __builtin_bit_cast(float, kSkipEnvBits);
 }
 
 // observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the

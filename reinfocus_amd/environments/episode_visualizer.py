@@ -111,8 +111,10 @@ class HistoryVisualizer:
     def visualize(self):
         """uint8[num_envs * 600, 600 + plot width, 3] (episode_visualizer.py:188-201)."""
         frames = np.asarray(self._renderer.render(self.FRAME))
+        # zip(renderings, graphs) in the reference: after a partial auto-reset render the shared
+        # renderer holds only the environments that were reset, and only that many rows come out
         rows = [np.concatenate([frames[i], self._visualize_single_history(i)], axis=1)
-                for i in range(self._num_envs)]
+                for i in range(min(len(frames), self._num_envs))]
         return np.concatenate(rows, axis=0)
 
     def _caption(self, env_index):

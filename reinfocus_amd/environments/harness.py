@@ -27,6 +27,26 @@ from reinfocus_amd.graphics import render
 TARGET, FOCUS = 0, 1  # state element indices (custom_environments.py:169-171)
 
 
+def _gymnasium_bases():
+    """(Env base, VectorEnv base): gymnasium's classes when gymnasium is importable -- the
+    reference's environments derive from gymnasium.Env (environments/environment.py:19) and
+    gymnasium.experimental.vector.VectorEnv (environments/vector_environment.py:19; plain
+    gymnasium.vector.VectorEnv from gymnasium 1.0 on), which gymnasium.make_vec, its wrappers and
+    the SB3 shim rely on -- otherwise `object` (this image has no gymnasium)."""
+    try:
+        import gymnasium
+    except ImportError:
+        return object, object
+    try:
+        from gymnasium.experimental.vector import VectorEnv  # gymnasium ~= 0.29 (pyproject.toml:29)
+    except ImportError:
+        from gymnasium.vector import VectorEnv
+    return gymnasium.Env, VectorEnv
+
+
+_EnvBase, _VectorEnvBase = _gymnasium_bases()
+
+
 class _Initializer:
     """Uniform states in `ends` (state_initializer.py:30-71, vectorised and seedable)."""
 
@@ -83,17 +103,33 @@ class _Ender:
         return l_status + (", " if l_status and r_status else "") + r_status
 
 
+def delta_bounds(lows, highs, max_change=None, include_original=False):
+    """Observation bounds of DeltaObserver (state_observer.py:166-230): a change is bounded by
+    high - low of what it is a change of, or by max_change where that is given (not NaN); with
+    include_original the wrapped bounds come first.  float32, as gymnasium's Box."""
+    lows = np.asarray(lows, dtype=np.float32)
+    highs = np.asarray(highs, dtype=np.float32)
+    diff = highs - lows
+    if max_change is not None:
+        max_change = np.asarray(max_change, dtype=np.float32)
+        diff = np.where(np.isnan(max_change), diff, max_change).astype(np.float32)
+    if include_original:
+        return np.append(lows, -diff), np.append(highs, diff)
+    return -diff, diff
+
+
+def normaliser_from_bounds(low, high):
+    """mid / scale of NormalizedObserver (state_observer.py:440-470): observations are mapped
+    from [low, high] to [-1, 1] as clip((x - mid) / scale, -1, 1); everything float32."""
+    spans = np.vstack([low, high]).astype(np.float32)
+    return np.average(spans, axis=0), np.diff(spans / 2, axis=0).reshape(spans.shape[1])
+
+
 def normaliser_constants(ends, max_move, min_focus, max_focus):
     """mid / scale of NormalizedObserver over DeltaObserver([IndexedElement, Focus], True,
-    [max_move, nan]) -- state_observer.py:166-230, :440-470; everything float32."""
-    lows = np.array([ends[0], min_focus], dtype=np.float32)
-    highs = np.array([ends[1], max_focus], dtype=np.float32)
-    diff = highs - lows
-    diff[0] = max_move
-    low = np.append(lows, -diff)
-    high = np.append(highs, diff)
-    spans = np.vstack([low, high]).astype(np.float32)
-    return np.average(spans, axis=0), np.diff(spans / 2, axis=0).reshape(4)
+    [max_move, nan]) -- custom_environments.py:196-218."""
+    low, high = delta_bounds([ends[0], min_focus], [ends[1], max_focus], [max_move, np.nan], True)
+    return normaliser_from_bounds(low, high)
 
 
 class _Observer:
@@ -158,16 +194,16 @@ class _Rewarder:
         return (moved + observations[:, self._o_index]) + on_target
 
 
-class VectorDiscreteSteps:
-    """The DiscreteSteps-v0 vector environment (custom_environments.py:114-241) on the
-    MI355X render path.  Same constructor arguments and defaults as the reference;
-    frame_height / samples_per_pixel / seed / device / first_state_index are extensions
-    (defaults = the reference's 300 px, 100 spp, device LOCAL_RANK)."""
+class _HostGlue:
+    """The DiscreteSteps task with the reference's numpy glue on the host around the GPU
+    render + focus (FocusObserver): everything VectorDiscreteSteps, DiscreteSteps and
+    ContinuousJumps share.  Not an environment class by itself."""
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
 
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
                  samples_per_pixel=100, seed=None, device=None, first_state_index=0, _diverging_only=False):
+        super().__init__()
         ends = (5.0, 10.0)
         target_radius = 0.25
         max_move = 5.0
@@ -255,10 +291,19 @@ class VectorDiscreteSteps:
         return np.asarray(self._renderer.render(600))
 
     def close(self):
-        self._renderer._ctx.close()
+        self._renderer.close()
 
 
-class DiscreteSteps(VectorDiscreteSteps):
+class VectorDiscreteSteps(_HostGlue, _VectorEnvBase):
+    """The DiscreteSteps-v0 vector environment (custom_environments.py:114-241) with the
+    reference's numpy glue on the host.  Same constructor arguments and defaults as the
+    reference; frame_height / samples_per_pixel / seed / device / first_state_index are
+    extensions (defaults = the reference's 300 px, 100 spp, device LOCAL_RANK).
+    DeviceVectorDiscreteSteps is the same environment with the glue on the GPU (the default of
+    registration.make_vec); results are identical bit for bit."""
+
+
+class DiscreteSteps(_HostGlue, _EnvBase):
     """The single-environment DiscreteSteps (custom_environments.py:16-111 on
     environments/environment.py): one env, DivergingEnder only, unbatched returns."""
 
@@ -282,7 +327,7 @@ class DiscreteSteps(VectorDiscreteSteps):
         return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
 
 
-class ContinuousJumps(VectorDiscreteSteps):
+class ContinuousJumps(_HostGlue, _EnvBase):
     """The single-environment ContinuousJumps (examples/custom_environments.py:244-339):
     one continuous action in [-1, 1] jumps the focus plane to the proportional position in
     [5, 10] unless the jump is shorter than target_radius / 2
@@ -324,77 +369,131 @@ class ContinuousJumps(VectorDiscreteSteps):
         return observations[0], reward, self._ender.is_terminated()[0], self._ender.is_truncated()[0], {}
 
 
-class DeviceVectorDiscreteSteps:
-    """VectorDiscreteSteps with the whole step resident on the GPU (rf_env_*, SURVEY.md
-    section 8(f) item 1): same constructor, same reset/step results bit for bit, but a step
-    only uploads the actions and the initializer's candidate states and downloads
-    observations, rewards and flags.  The initializer stays on the host (numpy PCG64DXSM):
-    a copy of the generator proposes num_envs candidate states per step, the device hands
-    row r to the r-th environment that ended, and the real generator then draws exactly the
-    rows that were used -- the same consumption as VectorDiscreteSteps."""
+class _DeviceShard:
+    """One rf_ctx holding a contiguous range of device-resident DiscreteSteps environments
+    (rf_env_*): the context, its RNG states at `first_state_index`, and the rf_env_config of the
+    task (custom_environments.py:166-241).  DeviceVectorDiscreteSteps owns one,
+    ShardedVectorDiscreteSteps one per device."""
 
-    metadata = {"render_modes": [], "render_fps": 4}
+    ENDS = (5.0, 10.0)
+    TARGET_RADIUS = 0.25
+    MAX_MOVE = 5.0
 
-    def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
-                 samples_per_pixel=100, seed=None, device=None, first_state_index=0):
-        import copy
+    def __init__(self, num_envs, max_episode_steps, frame_height, samples_per_pixel, device, first_state_index):
         import math
 
         from reinfocus_amd import _native, vision
         from reinfocus_amd.graphics import camera
 
-        assert render_mode is None, "the device-resident environment has no visualiser"
-        self.render_mode = None
-        self._copy = copy
-        ends = (5.0, 10.0)
-        target_radius = 0.25
-        max_move = 5.0
-        moves = max_move / 2.0 ** np.arange(6)
+        moves = self.MAX_MOVE / 2.0 ** np.arange(6)
+        self.action_set = np.concatenate([-moves, [0], moves[::-1]])
         self.num_envs = num_envs
-        self._limits = ends
-        self._initializer = _Initializer(ends, seed)
-        self._action_set = np.concatenate([-moves, [0], moves[::-1]])
+        self.frame_height = frame_height
+        self.samples_per_pixel = samples_per_pixel
+        self.first_state_index = int(first_state_index)
+        self.max_episode_steps = max_episode_steps
+        self.ctx = _native.Context(device)
+        try:
+            min_focus, max_focus = state_observer.cached_focus_extrema(self.ENDS, frame_height, samples_per_pixel,
+                                                                       self.ctx.device)
+            box = spaces.Box(min_focus, max_focus, dtype=np.float32)  # float32 rounding of the extrema
+            mid, scale = normaliser_constants(self.ENDS, self.MAX_MOVE, box.low[0], box.high[0])
+            cams = camera.FastCameras()
+            cfg = _native.EnvConfig()
+            cfg.n = num_envs
+            cfg.n_actions = len(self.action_set)
+            for i, a in enumerate(self.action_set):
+                cfg.action_set[i] = float(a)
+            cfg.limit_lo, cfg.limit_hi = self.ENDS
+            cfg.max_steps = max_episode_steps if max_episode_steps else 0
+            cfg.diverge_threshold = self.TARGET_RADIUS / 2
+            cfg.early_end_steps = 3
+            for i in range(4):
+                cfg.mid[i] = float(mid[i])
+                cfg.scale[i] = float(scale[i])
+            cfg.reward_scale = self.TARGET_RADIUS * 2
+            cfg.on_target_span = self.TARGET_RADIUS
+            cfg.half_width = cams._half_width
+            cfg.half_height = cams._half_height
+            cfg.tan_half_r = math.tan(math.radians(20 / 2))
+            for i in range(3):
+                cfg.look_from[i] = float(cams._look_from[i])
+                cfg.cam_u[i] = float(cams._u[i])
+                cfg.cam_v[i] = float(cams._v[i])
+                cfg.cam_w[i] = float(cams._w[i])
+            cfg.lens_radius = float(cams._half_aperture)
+            cfg.frame_height = frame_height
+            cfg.spp = samples_per_pixel
+            cfg.gray_mode = vision.GRAY_MODE
+            self.ctx.seed(num_envs * frame_height * frame_height, 0, self.first_state_index)
+            self.ctx.env_configure(cfg)
+        except Exception:
+            self.ctx.close()
+            raise
 
-        self._ctx = _native.Context(device)
-        min_focus, max_focus = state_observer.cached_focus_extrema(ends, frame_height, samples_per_pixel,
-                                                                   self._ctx.device)
-        box = spaces.Box(min_focus, max_focus, dtype=np.float32)  # float32 rounding of the extrema
-        mid, scale = normaliser_constants(ends, max_move, box.low[0], box.high[0])
-        cams = camera.FastCameras()
-        cfg = _native.EnvConfig()
-        cfg.n = num_envs
-        cfg.n_actions = len(self._action_set)
-        for i, a in enumerate(self._action_set):
-            cfg.action_set[i] = float(a)
-        cfg.limit_lo, cfg.limit_hi = ends
-        cfg.max_steps = max_episode_steps if max_episode_steps else 0
-        cfg.diverge_threshold = target_radius / 2
-        cfg.early_end_steps = 3
-        for i in range(4):
-            cfg.mid[i] = float(mid[i])
-            cfg.scale[i] = float(scale[i])
-        cfg.reward_scale = target_radius * 2
-        cfg.on_target_span = target_radius
-        cfg.half_width = cams._half_width
-        cfg.half_height = cams._half_height
-        cfg.tan_half_r = math.tan(math.radians(20 / 2))
-        for i in range(3):
-            cfg.look_from[i] = float(cams._look_from[i])
-            cfg.cam_u[i] = float(cams._u[i])
-            cfg.cam_v[i] = float(cams._v[i])
-            cfg.cam_w[i] = float(cams._w[i])
-        cfg.lens_radius = float(cams._half_aperture)
-        cfg.frame_height = frame_height
-        cfg.spp = samples_per_pixel
-        cfg.gray_mode = vision.GRAY_MODE
-        self._ctx.seed(num_envs * frame_height * frame_height, 0, first_state_index)
-        self._ctx.env_configure(cfg)
+    # -- what HistoryVisualizer needs from a renderer / an ender (episode_visualizer.py:197, :268) --
+    def render(self, frame_height):
+        """FastRenderer.render on the renderer the reference's FocusObserver and visualiser share
+        (render.py:165-188, :248-257): the scene set uploaded last, states re-created from seed 0
+        when more are needed than exist."""
+        needed = self.ctx.env_scene_len() * frame_height * frame_height
+        if self.ctx.num_states() < needed:
+            self.ctx.seed(needed, 0, self.first_state_index)
+        return self.ctx.env_render(frame_height, self.samples_per_pixel)
 
-        self.single_action_space = spaces.Discrete(len(self._action_set))
-        self.action_space = spaces.batch_space(self.single_action_space, num_envs)
-        self.single_observation_space = spaces.Box(-np.ones(4, dtype=np.float32), np.ones(4, dtype=np.float32),
-                                                   dtype=np.float32)
-        self.observation_space = spaces.batch_space(self.single_observation_space, num_envs)
+    def status(self, index):
+        """_Ender.status from the counters on the device."""
+        steps, diverging = self.ctx.env_counters()
+        r_status = f"diverging {diverging[index]} / 3" if diverging[index] > 0 else ""
+        if not self.max_episode_steps:
+            return r_status
+        l_status = f"step {steps[index]} / {self.max_episode_steps}"
+        return l_status + (", " if l_status and r_status else "") + r_status
+
+
+def _device_spaces(env, action_set, num_envs):
+    env.single_action_space = spaces.Discrete(len(action_set))
+    env.action_space = spaces.batch_space(env.single_action_space, num_envs)
+    env.single_observation_space = spaces.Box(-np.ones(4, dtype=np.float32), np.ones(4, dtype=np.float32),
+                                              dtype=np.float32)
+    env.observation_space = spaces.batch_space(env.single_observation_space, num_envs)
+
+
+class DeviceVectorDiscreteSteps(_VectorEnvBase):
+    """VectorDiscreteSteps with the whole step resident on the GPU (rf_env_*, SURVEY.md
+    section 8(f) item 1): same constructor, same reset/step results bit for bit, but a step
+    only uploads the actions and the initializer's candidate states and downloads
+    observations, rewards and flags.  This is what `DiscreteSteps-v0`'s vector entry point
+    builds.  The initializer stays on the host (numpy PCG64DXSM): a copy of the generator
+    proposes num_envs candidate states per step, the device hands row r to the r-th environment
+    that ended, and the real generator then draws exactly the rows that were used -- the same
+    consumption as VectorDiscreteSteps.  render_mode="rgb_array" works as in the reference
+    (HistoryVisualizer on the environment's own renderer state: the 600 px render advances /
+    re-seeds the RNG states the next step uses)."""
+
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
+
+    def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
+                 samples_per_pixel=100, seed=None, device=None, first_state_index=0):
+        import copy
+
+        super().__init__()
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        self.render_mode = render_mode
+        self._copy = copy
+        self.num_envs = num_envs
+        self._shard = _DeviceShard(num_envs, max_episode_steps, frame_height, samples_per_pixel, device,
+                                   first_state_index)
+        self._ctx = self._shard.ctx
+        self._limits = _DeviceShard.ENDS
+        self._initializer = _Initializer(self._limits, seed)
+        self._action_set = self._shard.action_set
+        _device_spaces(self, self._action_set, num_envs)
+        self._visualizer = None
+        if render_mode == "rgb_array":  # custom_environments.py:229-238
+            self._visualizer = episode_visualizer.HistoryVisualizer(
+                num_envs, TARGET, FOCUS, 1, self._shard, self._limits, ender=self._shard,
+                target_radius=_DeviceShard.TARGET_RADIUS)
 
     @property
     def _state(self):
@@ -405,7 +504,10 @@ class DeviceVectorDiscreteSteps:
             self._initializer = _Initializer(self._limits, seed)
         initial = (self._initializer.initialize(self.num_envs) if state is None
                    else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
-        return self._ctx.env_reset(initial), {}
+        observations = self._ctx.env_reset(initial)
+        if self._visualizer is not None:
+            self._visualizer.reset(initial, observations)
+        return observations, {}
 
     def step(self, actions):
         generator = self._initializer._generator
@@ -414,10 +516,139 @@ class DeviceVectorDiscreteSteps:
         observations, rewards, truncated, used = self._ctx.env_step(actions, pool)
         if used:
             self._initializer.initialize(used)  # consume exactly the rows that were used
+        if self._visualizer is not None:  # vector_environment.py:149-156
+            state = self._state
+            if used:
+                self._visualizer.reset(state[truncated], observations[truncated], truncated)
+            self._visualizer.step(state[~truncated], observations[~truncated], ~truncated)
         return observations, rewards, np.full(self.num_envs, False), truncated, {}
+
+    def render(self):
+        """vector_environment.py:166-176."""
+        if self._visualizer is not None:
+            return self._visualizer.visualize()
+        return None
+
+    def render_frames(self):
+        """Only the left halves of render(): the 600 px frames of the scene set uploaded last."""
+        return self._shard.render(episode_visualizer.HistoryVisualizer.FRAME)
+
+    def close(self):
+        self._ctx.close()
+
+
+def split_environments(num_envs, shards):
+    """Contiguous env ranges [first, first + count) per shard, as even as possible."""
+    counts = [num_envs // shards + (1 if g < num_envs % shards else 0) for g in range(shards)]
+    firsts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(int)
+    return [(int(f), int(c)) for f, c in zip(firsts, counts)]
+
+
+class ShardedVectorDiscreteSteps(_VectorEnvBase):
+    """DeviceVectorDiscreteSteps over several GPUs of one node (the
+    reference has no counterpart: vector_environment.py:104-164 steps all environments on one
+    device).  Environments are independent, so device g owns the contiguous range
+    [first_g, first_g + n_g) -- one rf_ctx and one host thread per device (ctypes releases the
+    GIL), no device-to-device traffic, the host concatenates observations / rewards / flags
+    (8 + 16 + 1 bytes per environment).
+
+    RNG states: shard g is seeded at global state index first_state_index + first_g * h * h
+    (pixel index = e * h * w + y * w + x, render.py:217), so full renders draw exactly what one
+    device holding all environments would draw.  Initializer: one generator for the whole
+    environment; the r-th environment that ended, in global index order, takes the r-th drawn
+    state, as on one device -- which is why a step has two halves (rf_env_step_begin /
+    rf_env_step_end): the rows a shard takes depend on how many environments ended before it.
+    Deviation (documented in DESIGN.md section 6): the partial render of an auto-reset re-indexes
+    its RNG states from the shard's own base instead of from the global state 0 of the compacted
+    done set (render.py:217 on vector_environment.py:144's compacted rows), so after the first
+    auto-reset the sharded run and the one-device run are different -- equally valid -- sample
+    paths.  `devices` may name a device more than once (several contexts on one GPU: tests)."""
+
+    metadata = {"render_modes": [], "render_fps": 4}
+
+    def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, devices=None, frame_height=300,
+                 samples_per_pixel=100, seed=None, first_state_index=0):
+        import concurrent.futures
+        import copy
+
+        from reinfocus_amd import _native
+
+        super().__init__()
+        assert render_mode is None, "the sharded environment has no visualiser (use DeviceVectorDiscreteSteps)"
+        self.render_mode = None
+        self._copy = copy
+        if devices is None:
+            devices = list(range(_native.device_count()))
+        devices = [int(d) for d in devices]
+        assert 1 <= len(devices) <= num_envs, "need between 1 and num_envs devices"
+        self.num_envs = num_envs
+        self.devices = devices
+        self._ranges = split_environments(num_envs, len(devices))
+        self._limits = _DeviceShard.ENDS
+        self._initializer = _Initializer(self._limits, seed)
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(devices),
+                                                           thread_name_prefix="reinfocus-shard")
+        pixels = frame_height * frame_height
+        self._shards = []
+        try:
+            futures = [self._pool.submit(_DeviceShard, count, max_episode_steps, frame_height, samples_per_pixel,
+                                         device, first_state_index + first * pixels)
+                       for device, (first, count) in zip(devices, self._ranges)]
+            for future in futures:
+                try:
+                    self._shards.append(future.result())
+                except Exception:
+                    for other in futures:
+                        if other.done() and other.exception() is None:
+                            other.result().ctx.close()
+                    raise
+        except Exception:
+            self._pool.shutdown(wait=True)
+            raise
+        self._action_set = self._shards[0].action_set
+        _device_spaces(self, self._action_set, num_envs)
+
+    def _each(self, function, *per_shard):
+        """function(shard, *args_g) on every shard's own thread; results in shard order."""
+        futures = [self._pool.submit(function, shard, *(a[g] for a in per_shard))
+                   for g, shard in enumerate(self._shards)]
+        return [f.result() for f in futures]
+
+    def _slices(self, array):
+        return [array[first:first + count] for first, count in self._ranges]
+
+    @property
+    def _state(self):
+        return np.concatenate(self._each(lambda shard: shard.ctx.env_states()))
+
+    def reset(self, *, seed=None, options=None, state=None):
+        if seed is not None:
+            self._initializer = _Initializer(self._limits, seed)
+        initial = (self._initializer.initialize(self.num_envs) if state is None
+                   else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
+        observations = self._each(lambda shard, rows: shard.ctx.env_reset(rows), self._slices(initial))
+        return np.concatenate(observations), {}
+
+    def step(self, actions):
+        actions = np.asarray(actions).reshape(self.num_envs)
+        proposal = self._copy.deepcopy(self._initializer._generator)
+        pool = proposal.uniform(self._limits[0], self._limits[1], size=(self.num_envs, 2)).astype(np.float32)
+        firsts = self._each(lambda shard, a: shard.ctx.env_step_begin(a), self._slices(actions))
+        ended = [k for _, _, k in firsts]
+        starts = np.concatenate([[0], np.cumsum(ended)]).astype(int)
+        rows = [pool[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
+        observations = self._each(lambda shard, r: shard.ctx.env_step_end(r), rows)
+        if starts[-1]:
+            self._initializer.initialize(int(starts[-1]))  # consume exactly the rows that were used
+        rewards = np.concatenate([r for r, _, _ in firsts])
+        truncated = np.concatenate([t for _, t, _ in firsts])
+        return np.concatenate(observations), rewards, np.full(self.num_envs, False), truncated, {}
 
     def render(self):
         return None
 
     def close(self):
-        self._ctx.close()
+        for shard in self._shards:
+            shard.ctx.close()
+        self._shards = []
+        self._pool.shutdown(wait=True)

@@ -37,9 +37,12 @@ class BaseObserver:
 def _focus_extrema(ends, frame_height, samples_per_pixel, device):
     max_targets = np.linspace(*ends, 11)
     renderer = render.FastRenderer(samples_per_pixel=samples_per_pixel, device=device)
-    renderer.update_targets(np.append(ends, max_targets))
-    renderer.update_focus_planes(np.append(ends[::-1], max_targets))
-    focus_values = vision.focus_values(renderer.render(frame_height))
+    try:
+        renderer.update_targets(np.append(ends, max_targets))
+        renderer.update_focus_planes(np.append(ends[::-1], max_targets))
+        focus_values = vision.focus_values(renderer.render(frame_height))
+    finally:
+        renderer.close()  # the fresh renderer of state_observer.py:314 is garbage afterwards
     return min(focus_values[0:2]), max(focus_values[2:13])
 
 

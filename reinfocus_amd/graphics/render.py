@@ -87,6 +87,13 @@ class FastRenderer:
         self._generation = 0
         self._last_frames = None
 
+    def close(self):
+        """Releases the rf_ctx (device memory); frames still referenced are copied out first."""
+        last = self._last_frames() if self._last_frames is not None else None
+        if last is not None:
+            last._detach()
+        self._ctx.close()
+
     def update_targets(self, targets):
         """render.py:147-154."""
         self._worlds.update(targets)

@@ -17,10 +17,23 @@ _scratch = None
 
 
 def _scratch_context():
+    """Context that scores host arrays (one per process, created on first use, released by
+    release() or at interpreter exit)."""
     global _scratch
     if _scratch is None:
+        import atexit
+
         _scratch = _native.Context()
+        atexit.register(release)
     return _scratch
+
+
+def release():
+    """Frees the scratch context's device memory; the next host-array call makes a new one."""
+    global _scratch
+    if _scratch is not None:
+        _scratch.close()
+        _scratch = None
 
 
 def focus_values(images):

@@ -1,6 +1,7 @@
-"""The N > 1 path of bench.py on CPU: two ranks over gloo (torch.distributed.run,
-127.0.0.1), env sharding plan, barrier + max-over-ranks timing, one JSON line from rank 0.
-No GPU work happens in --plumbing-test mode and the line says so."""
+"""The N > 1 path of bench.py on CPU: two ranks over gloo -- launched by bench.py itself
+(`python bench.py --gpus 2`, what the driver runs) and by torch.distributed.run --, env sharding
+plan, barrier + max-over-ranks timing, one JSON line from rank 0, a failing rank failing the
+launch.  No GPU work happens in --plumbing-test mode and the line says so."""
 
 import json
 import os
@@ -45,3 +46,44 @@ def test_two_ranks_over_gloo():
     assert line["n_gpus"] == 2
     assert line["config"]["total_envs"] == 2 * line["config"]["envs_per_gpu"]
     assert line["ms_per_step"] > 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it: the parent starts the two ranks
+    (before anything could touch a GPU), relays rank 0's line and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4
+    assert line["config"]["total_envs"] == 2 * line["config"]["envs_per_gpu"]
+    assert "one process per GPU" in line["config"]["sharding"]
+
+
+def test_a_failing_rank_fails_the_launch():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["REINFOCUS_BENCH_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "2", "--warmup", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert "rank 1 exited with code 3" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_parent_launcher_never_loads_the_hip_library():
+    """The launching parent must not initialise the GPU (a process that has may not hand over to
+    others on this pool): launch_ranks is reached before reinfocus_amd._native is imported."""
+    import ast
+
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    launch_line = next(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call)
+                       and getattr(n.func, "id", "") == "launch_ranks")
+    native_lines = [n.lineno for n in ast.walk(main) if isinstance(n, ast.ImportFrom) and n.module
+                    and n.module.startswith("reinfocus_amd")]
+    assert native_lines and launch_line < min(native_lines)
+    top_level = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any("reinfocus_amd" in ast.dump(n) or "torch" in ast.dump(n) for n in top_level)

@@ -228,3 +228,163 @@ def test_sb3_wrapper_over_device_environment():
     assert wrapped.get_images() == [None]
     wrapped.close()
     plain.close()
+
+
+def test_registered_vector_env_is_device_resident_and_reproduces_the_notebook():
+    """The env id's vector entry point (examples/__init__.py:6-11) builds the device-resident
+    environment -- the one bench.py measures -- and, with render_mode="rgb_array", that environment
+    prints the reference notebook's digits (see test_reference_notebook_outputs): rf_env_reset,
+    the visualiser's 600 px render through rf_env_render (which re-seeds), rf_env_step."""
+    from reinfocus_amd import registration
+    from reinfocus_amd.environments import harness
+
+    env = registration.make_vec("DiscreteSteps-v0", num_envs=1, vectorization_mode="custom",
+                                vector_kwargs={"render_mode": "rgb_array", "device": 0})
+    assert type(env) is harness.DeviceVectorDiscreteSteps and env.render_mode == "rgb_array"
+    obs, _ = env.reset(state=[[5.311405, 8.66759]])
+    assert repr(obs[0]) == "array([ 0.46703607, -0.84483975,  0.        ,  0.        ], dtype=float32)"
+    image = env.render()
+    assert image.shape == (600, 1400, 3) and image.dtype == np.uint8
+    centre = image[250:350, 250:350]
+    assert np.all(centre[..., 2] == 0) and np.all(centre[..., 0].astype(int) + centre[..., 1] > 0)
+    obs, reward, terminated, truncated, _ = env.step(np.array([8]))
+    assert repr(obs[0]) == "array([ 0.59203607, -0.873161  ,  0.0625    , -0.01416067], dtype=float32)"
+    assert reward[0] == -1.4981610774993896
+    assert not terminated[0] and not truncated[0]
+    assert np.array_equal(env._state, np.array([[5.311405, 8.98009]], dtype=np.float32))
+    env.close()
+    # the numpy-glue environment stays reachable under the same id
+    host = registration.make_vec("DiscreteSteps-v0", num_envs=2, glue="host", frame_height=16, samples_per_pixel=1,
+                                 device=0)
+    assert type(host) is harness.VectorDiscreteSteps
+    host.close()
+
+
+def test_device_environment_visualiser_equals_host_glue():
+    """render_mode="rgb_array" on the device-resident environment: same frames from render(), same
+    observations afterwards (the 600 px render advances / re-seeds the RNG states), same rows after
+    a partial auto-reset (the shared renderer then holds only the environments that were reset,
+    vector_environment.py:144 + episode_visualizer.py:197-201) as the numpy-glue environment."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(max_episode_steps=3, num_envs=4, render_mode="rgb_array", frame_height=32, samples_per_pixel=2,
+              seed=9, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    assert np.array_equal(host.reset()[0], dev.reset()[0])
+    rng = np.random.default_rng(1)
+    rows_seen = set()
+    for step in range(7):
+        a, b = host.render(), dev.render()
+        assert a.shape == b.shape and a.shape[0] % 600 == 0
+        assert np.array_equal(a[:, :600], b[:, :600])  # the rendered frames (plots are matplotlib's)
+        rows_seen.add(a.shape[0] // 600)
+        actions = rng.integers(0, 13, 4)
+        want, got = host.step(actions), dev.step(actions)
+        for x, y in zip(want[:4], got[:4]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(host._state, dev._state)
+        for i in range(4):
+            assert host._ender.status(i) == dev._shard.status(i)
+        assert np.array_equal(host._visualizer._current_moves, dev._visualizer._current_moves)
+        assert np.array_equal(host._visualizer._targets, dev._visualizer._targets)
+    assert 4 in rows_seen and len(rows_seen) > 1  # full sets and at least one partial (auto-reset) set
+    host.close()
+    dev.close()
+
+
+def _toward_target(state, action_set):
+    """An action per environment that never grows |target - focus| (nobody diverges)."""
+    gap = state[:, 0] - state[:, 1]
+    step = 0.15625
+    return np.where(gap > step, 7, np.where(gap < -step, 5, 6)).astype(np.int64)
+
+
+@pytest.mark.parametrize("n,shards", [(12, 2), (7, 3)])
+def test_sharded_environment_equals_one_device(n, shards):
+    """harness.ShardedVectorDiscreteSteps with several contexts on device 0 against ONE
+    DeviceVectorDiscreteSteps holding all environments: bit-identical observations, rewards and
+    states while renders are full ones (global RNG-state indices via rf_seed's first_state_index);
+    after auto-resets (documented deviation: partial renders index their states per shard) the
+    initializer's states still go to the ended environments in GLOBAL index order."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(max_episode_steps=6, num_envs=n, frame_height=24, samples_per_pixel=3, seed=21)
+    one = harness.DeviceVectorDiscreteSteps(device=0, **kw)
+    many = harness.ShardedVectorDiscreteSteps(devices=[0] * shards, **kw)
+    assert [c for _, c in many._ranges] == [n // shards + (1 if g < n % shards else 0) for g in range(shards)]
+    o1, _ = one.reset()
+    o2, _ = many.reset()
+    assert o2.dtype == np.float32 and np.array_equal(o1, o2)
+    assert np.array_equal(one._state, many._state)
+    for _ in range(5):  # full renders only: nobody diverges, the time limit is at step 6
+        actions = _toward_target(one._state, one._action_set)
+        a, b = one.step(actions), many.step(actions)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        assert not b[3].any() and np.array_equal(one._state, many._state)
+    # step 6: every environment ends; both draw the same n states for them, in index order
+    a, b = one.step(np.full(n, 6)), many.step(np.full(n, 6))
+    assert a[3].all() and b[3].all() and np.array_equal(a[1], b[1])
+    assert np.array_equal(one._state, many._state)
+    assert one._initializer._generator.bit_generator.state == many._initializer._generator.bit_generator.state
+    # from here on the two are different sample paths; the sharded one keeps its invariants, and a
+    # twin generator predicts the states its ended environments receive
+    twin = harness._Initializer((5.0, 10.0), 21)
+    twin.initialize(n)
+    twin.initialize(n)
+    rng = np.random.default_rng(3)
+    ended = 0
+    for _ in range(8):
+        actions = rng.integers(0, 13, n)
+        obs, rewards, terminated, truncated, _ = many.step(actions)
+        assert obs.shape == (n, 4) and np.all(np.abs(obs) <= 1) and not terminated.any()
+        k = int(truncated.sum())
+        if k:
+            assert np.array_equal(many._state[truncated], twin.initialize(k))
+            assert np.all(obs[truncated, 2:] == 0)
+        ended += k
+    assert ended > 0
+    one.close()
+    many.close()
+
+
+def test_two_phase_step_guards():
+    """rf_env_step_begin / rf_env_step_end must alternate; rf_env_step refuses an open step."""
+    from reinfocus_amd.environments import harness
+
+    env = harness.DeviceVectorDiscreteSteps(num_envs=3, frame_height=16, samples_per_pixel=1, seed=0, device=0)
+    env.reset()
+    ctx = env._ctx
+    with pytest.raises(AssertionError):
+        ctx.env_step_end(np.zeros((0, 2), dtype=np.float32))
+    rewards, truncated, k = ctx.env_step_begin(np.full(3, 6))
+    assert k == 0 and not truncated.any() and rewards.shape == (3,)
+    with pytest.raises(AssertionError):
+        ctx.env_step_begin(np.full(3, 6))
+    with pytest.raises(AssertionError):
+        ctx.env_step(np.full(3, 6), np.zeros((3, 2), dtype=np.float32))
+    obs = ctx.env_step_end(np.zeros((0, 2), dtype=np.float32))
+    assert obs.shape == (3, 4)
+    env.step(np.full(3, 6))
+    env.close()
+
+
+def test_env_step_graph_capture_failure_falls_back(monkeypatch):
+    """rf_env_step's hipGraph branch when instantiation fails (REINFOCUS_ENV_GRAPH_FAIL=1 makes the
+    first one fail): the step is enqueued call by call from then on, with identical results."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(num_envs=40, frame_height=32, samples_per_pixel=2, seed=6, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    monkeypatch.setenv("REINFOCUS_ENV_GRAPH_FAIL", "1")
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    monkeypatch.delenv("REINFOCUS_ENV_GRAPH_FAIL")
+    assert np.array_equal(host.reset()[0], dev.reset()[0])
+    rng = np.random.default_rng(12)
+    for _ in range(12):
+        actions = rng.integers(0, 13, 40)
+        for x, y in zip(host.step(actions)[:4], dev.step(actions)[:4]):
+            assert np.array_equal(x, y)
+    host.close()
+    dev.close()

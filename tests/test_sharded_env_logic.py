@@ -1,0 +1,205 @@
+"""Host logic of harness.ShardedVectorDiscreteSteps and of the gymnasium base classes, on the CPU.
+
+The shards' rf_ctx is replaced by a numpy stand-in with the two-phase step protocol
+(env_step_begin / env_step_end); what is under test is what the sharded environment adds:
+contiguous env ranges, global RNG-state offsets, one thread per shard, the initializer's rows
+handed out in GLOBAL index order across shards, host concatenation.  The real thing runs in
+tests/test_gpu_environment.py::test_sharded_environment_equals_one_device."""
+
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeContext:
+    """The part of _native.Context a shard uses, in numpy: an environment ends every
+    `period[e]` steps; observations encode (state, steps) so that mix-ups are visible."""
+
+    def __init__(self, n, first_env):
+        self.n = n
+        self.period = 2 + (np.arange(first_env, first_env + n) % 3)
+        self.state = np.zeros((n, 2), dtype=np.float32)
+        self.steps = np.zeros(n, dtype=np.int64)
+        self.pending = None
+        self.closed = False
+
+    def _obs(self):
+        return np.column_stack([self.state, self.steps, self.steps * 0]).astype(np.float32)
+
+    def env_reset(self, states):
+        self.state = np.array(states, dtype=np.float32).reshape(self.n, 2)
+        self.steps[:] = 0
+        return self._obs()
+
+    def env_step_begin(self, actions):
+        assert self.pending is None
+        self.state[:, 1] += np.asarray(actions, dtype=np.float32) * 0.125
+        self.steps += 1
+        truncated = self.steps >= self.period
+        self.pending = truncated
+        return self.state.sum(axis=1).astype(np.float64), truncated.copy(), int(truncated.sum())
+
+    def env_step_end(self, rows):
+        truncated, self.pending = self.pending, None
+        rows = np.asarray(rows, dtype=np.float32).reshape(-1, 2)
+        assert len(rows) == truncated.sum()
+        self.state[truncated] = rows
+        self.steps[truncated] = 0
+        return self._obs()
+
+    def env_states(self):
+        return self.state.copy()
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.fixture()
+def fake_shards(monkeypatch):
+    from reinfocus_amd import _native
+    from reinfocus_amd.environments import harness
+
+    made = []
+
+    class FakeShard:
+        ENDS, TARGET_RADIUS, MAX_MOVE = harness._DeviceShard.ENDS, 0.25, 5.0
+        action_set = np.arange(13, dtype=np.float64)
+
+        def __init__(self, num_envs, max_episode_steps, frame_height, samples_per_pixel, device, first_state_index):
+            assert first_state_index % (frame_height * frame_height) == 0
+            self.first_env = first_state_index // (frame_height * frame_height)
+            self.num_envs, self.device = num_envs, device
+            self.ctx = FakeContext(num_envs, self.first_env)
+            made.append(self)
+
+    monkeypatch.setattr(harness, "_DeviceShard", FakeShard)
+    monkeypatch.setattr(_native, "device_count", lambda: 4)
+    return made
+
+
+def test_split_environments():
+    from reinfocus_amd.environments import harness
+
+    assert harness.split_environments(10, 3) == [(0, 4), (4, 3), (7, 3)]
+    assert harness.split_environments(32768, 8) == [(g * 4096, 4096) for g in range(8)]  # BASELINE configs[3]
+    assert harness.split_environments(3, 3) == [(0, 1), (1, 1), (2, 1)]
+
+
+@pytest.mark.parametrize("n,devices", [(11, [0, 1, 2]), (8, [0, 1, 2, 3]), (5, [3])])
+def test_sharded_step_equals_one_shard(fake_shards, n, devices):
+    from reinfocus_amd.environments import harness
+
+    many = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=devices, frame_height=16, samples_per_pixel=1, seed=4)
+    shards = [s for s in fake_shards]
+    assert [s.device for s in shards] == devices
+    assert [(s.first_env, s.num_envs) for s in shards] == harness.split_environments(n, len(devices))
+    one = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=[0], frame_height=16, samples_per_pixel=1, seed=4)
+    assert many.observation_space.shape == (n, 4) and many.single_action_space.n == 13
+    o1, _ = one.reset()
+    o2, info = many.reset()
+    assert info == {} and np.array_equal(o1, o2)
+    rng = np.random.default_rng(0)
+    total = 0
+    for _ in range(12):
+        actions = rng.integers(0, 13, n)
+        a, b = one.step(actions), many.step(actions)
+        for x, y in zip(a[:4], b[:4]):
+            assert x.shape == y.shape and np.array_equal(x, y)
+        assert np.array_equal(one._state, many._state)
+        total += int(b[3].sum())
+    assert total > n  # every environment ended at least once, in different steps
+    # same number of initializer draws: the rows went out in global index order
+    assert one._initializer._generator.bit_generator.state == many._initializer._generator.bit_generator.state
+    many.close()
+    one.close()
+    assert all(s.ctx.closed for s in fake_shards)
+
+
+def test_sharded_defaults_and_guards(fake_shards):
+    from reinfocus_amd import registration
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=8, frame_height=8, samples_per_pixel=1)
+    assert env.devices == [0, 1, 2, 3]  # every visible device by default
+    env.close()
+    with pytest.raises(AssertionError):
+        harness.ShardedVectorDiscreteSteps(num_envs=2, devices=[0, 1, 2], frame_height=8)
+    with pytest.raises(AssertionError):
+        harness.ShardedVectorDiscreteSteps(num_envs=4, devices=[0], render_mode="rgb_array", frame_height=8)
+    # the env id reaches it through `devices`
+    env = registration.make_vec("DiscreteSteps-v0", num_envs=6, devices=[0, 1], frame_height=8, samples_per_pixel=1)
+    assert type(env) is harness.ShardedVectorDiscreteSteps and env.num_envs == 6
+    env.close()
+
+
+def test_registration_builds_the_device_resident_environment(monkeypatch):
+    """make_vec / the gymnasium vector_entry_point build DeviceVectorDiscreteSteps unless glue="host"."""
+    from reinfocus_amd import registration
+    from reinfocus_amd.environments import harness
+
+    built = []
+    monkeypatch.setattr(harness, "DeviceVectorDiscreteSteps", lambda *a, **k: built.append(("device", a, k)) or "dev")
+    monkeypatch.setattr(harness, "VectorDiscreteSteps", lambda *a, **k: built.append(("host", a, k)) or "host")
+    assert registration.make_vec("DiscreteSteps-v0", 7, vector_kwargs={"render_mode": "rgb_array"}) == "dev"
+    assert built[-1] == ("device", (20, 7, "rgb_array"), {})
+    assert registration.make_vec("DiscreteSteps-v0", 3, vector_kwargs={"max_episode_steps": 5}, glue="host") == "host"
+    assert built[-1] == ("host", (5, 3, None), {})
+    assert registration.ENTRY_POINTS["DiscreteSteps-v0"]["vector_entry_point"] == "reinfocus_amd.registration:vector_discrete_steps"
+    with pytest.raises(AssertionError):
+        registration.make_vec("DiscreteSteps-v0", 2, vectorization_mode="sync")
+
+
+def test_environments_derive_from_gymnasium_when_it_is_importable(tmp_path):
+    """With a gymnasium on the path the environments are gymnasium.Env / VectorEnv subclasses (the
+    reference's are: environment.py:19, vector_environment.py:19) and the ids are registered with
+    it (examples/__init__.py:6-18).  This image has no gymnasium, so a minimal package with the
+    module layout of gymnasium 0.29 stands in; the check runs in a fresh interpreter."""
+    pkg = tmp_path / "gymnasium"
+    (pkg / "experimental" / "vector").mkdir(parents=True)
+    (pkg / "vector").mkdir()
+    (pkg / "envs").mkdir()
+    (pkg / "__init__.py").write_text("class Env:\n    pass\nfrom gymnasium import spaces\n")
+    (pkg / "spaces.py").write_text(textwrap.dedent("""
+        import numpy as np
+        class Box:
+            def __init__(self, low, high, shape=None, dtype=np.float32):
+                self.low = np.atleast_1d(np.asarray(low, dtype=dtype)); self.high = np.atleast_1d(np.asarray(high, dtype=dtype))
+                self.shape = self.low.shape; self.dtype = np.dtype(dtype)
+        class Discrete:
+            def __init__(self, n): self.n = n; self.shape = ()
+        class MultiDiscrete:
+            def __init__(self, nvec): self.nvec = nvec
+        """))
+    (pkg / "experimental" / "__init__.py").write_text("")
+    (pkg / "experimental" / "vector" / "__init__.py").write_text("class VectorEnv:\n    pass\n")
+    (pkg / "vector" / "__init__.py").write_text("")
+    (pkg / "vector" / "utils.py").write_text("def batch_space(space, n=1):\n    return ('batched', space, n)\n")
+    (pkg / "envs" / "__init__.py").write_text("")
+    (pkg / "envs" / "registration.py").write_text(
+        "registry = {}\ndef register(id, **spec):\n    registry[id] = spec\n")
+    code = textwrap.dedent("""
+        import gymnasium
+        from gymnasium.experimental.vector import VectorEnv
+        from gymnasium.envs import registration as gym_registration
+        from reinfocus_amd import registration
+        from reinfocus_amd.environments import harness, spaces
+        assert spaces.HAVE_GYMNASIUM
+        for cls in (harness.VectorDiscreteSteps, harness.DeviceVectorDiscreteSteps, harness.ShardedVectorDiscreteSteps):
+            assert issubclass(cls, VectorEnv), cls
+        for cls in (harness.DiscreteSteps, harness.ContinuousJumps):
+            assert issubclass(cls, gymnasium.Env) and not issubclass(cls, VectorEnv), cls
+        spec = gym_registration.registry["DiscreteSteps-v0"]
+        assert spec["max_episode_steps"] == 20 and spec["vector_entry_point"].endswith(":vector_discrete_steps")
+        assert spec["entry_point"].endswith(":DiscreteSteps")
+        assert gym_registration.registry["ContinuousJumps-v0"]["max_episode_steps"] == 20
+        print("ok")
+        """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-3000:]
