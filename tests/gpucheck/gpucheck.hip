@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../reinfocus_amd/csrc/rf_math.h"
+#include "probe_general.h"
 
 __global__ void check_range(uint32_t first_bits, uint32_t count, unsigned long long *bad /*[2]*/)
 {
@@ -50,4 +51,79 @@ extern "C" int gc_check_sqrt_rcp(unsigned long long out[3])
     out[2] = total;
     (void)hipFree(d_bad);
     return 0;
+}
+
+// ---- probes of the general renderer's float64 library calls (see probe_general.h) ----------
+__global__ void probe_f64_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = probe::f64_op(op, a[i], b[i]);
+}
+
+__global__ void probe_uv_kernel(const float *normals, float *uv, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        probe::sphere_uv(normals + 3 * i, uv + 2 * i);
+}
+
+__global__ void probe_checker_kernel(const float *f, const float *u, int *sign, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        sign[i] = rf::checker_sign_general(f[i], u[i]);
+}
+
+namespace {
+template <typename F>
+int with_buffers(const void *const *host_in, const size_t *in_bytes, int n_in, void *host_out, size_t out_bytes, F launch)
+{
+    void *d_in[3] = {nullptr, nullptr, nullptr}, *d_out = nullptr;
+    int rc = 0;
+    for (int i = 0; i < n_in && rc == 0; ++i) {
+        if (hipMalloc(&d_in[i], in_bytes[i]) != hipSuccess ||
+            hipMemcpy(d_in[i], host_in[i], in_bytes[i], hipMemcpyHostToDevice) != hipSuccess)
+            rc = -1;
+    }
+    if (rc == 0 && hipMalloc(&d_out, out_bytes) != hipSuccess)
+        rc = -1;
+    if (rc == 0) {
+        launch(d_in, d_out);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -2;
+    }
+    for (int i = 0; i < n_in; ++i)
+        if (d_in[i])
+            (void)hipFree(d_in[i]);
+    if (d_out)
+        (void)hipFree(d_out);
+    return rc;
+}
+} // namespace
+
+extern "C" int gc_probe_f64(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    const void *in[2] = {a, b};
+    const size_t bytes[2] = {n * 8, n * 8};
+    return with_buffers(in, bytes, 2, out, n * 8, [&](void **d, void *o) {
+        hipLaunchKernelGGL(probe_f64_kernel, dim3(1024), dim3(256), 0, 0, op, (const double *)d[0], (const double *)d[1],
+                           (double *)o, n);
+    });
+}
+
+extern "C" int gc_probe_uv(const float *normals, float *uv, uint64_t n)
+{
+    const void *in[1] = {normals};
+    const size_t bytes[1] = {n * 12};
+    return with_buffers(in, bytes, 1, uv, n * 8, [&](void **d, void *o) {
+        hipLaunchKernelGGL(probe_uv_kernel, dim3(1024), dim3(256), 0, 0, (const float *)d[0], (float *)o, n);
+    });
+}
+
+extern "C" int gc_probe_checker(const float *f, const float *u, int *sign, uint64_t n)
+{
+    const void *in[2] = {f, u};
+    const size_t bytes[2] = {n * 4, n * 4};
+    return with_buffers(in, bytes, 2, sign, n * 4, [&](void **d, void *o) {
+        hipLaunchKernelGGL(probe_checker_kernel, dim3(1024), dim3(256), 0, 0, (const float *)d[0], (const float *)d[1],
+                           (int *)o, n);
+    });
 }

@@ -9,6 +9,7 @@
 #include "../../reinfocus_amd/csrc/rf_math.h"
 #include "../../reinfocus_amd/csrc/rf_jump.h"
 #include "../../reinfocus_amd/csrc/rf_general.h"
+#include "../gpucheck/probe_general.h"
 
 using namespace rf;
 
@@ -272,6 +273,38 @@ int hs_state_at(uint64_t seed, uint64_t index, uint64_t out[2])
             s = h_matvec(tables[k], s);
     out[0] = s.s0;
     out[1] = s.s1;
+    return 0;
+}
+
+// host side of tests/gpucheck's probes (glibc's libm): same functions, same operands
+int hs_probe_f64(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = probe::f64_op(op, a[i], b[i]);
+    return 0;
+}
+
+int hs_probe_uv(const float *normals, float *uv, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        probe::sphere_uv(normals + 3 * i, uv + 2 * i);
+    return 0;
+}
+
+// the reference's expression itself: sign of sin(fl64(fl64(f * pi) * u)) with the real libm sin
+int hs_probe_checker_literal(const float *f, const float *u, int *sign, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const double s = sin(((double)f[i] * rf::kPi) * (double)u[i]);
+        sign[i] = s > 0.0 ? 1 : (s < 0.0 ? -1 : 0);
+    }
+    return 0;
+}
+
+int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        sign[i] = rf::checker_sign_general(f[i], u[i]);
     return 0;
 }
 
