@@ -8,10 +8,15 @@
 //   rectangle.hit / uv        graphics/rectangle.py:49-99, :151-170
 //   physics.find_colour       graphics/physics.py:95-145
 // with the same rounding points as the oracle (numba typing: math.* on f32 -> f64).
-// The float64 libm calls (sqrt, atan2, acos; sin only within 1e-9 of a checker edge) use
-// the device math library, which is not bit-identical to glibc in the last ulp; the
-// results pass through a float32 cast and a sign test, so frames equal the oracle's
-// except, potentially, at isolated pixels (tests allow none on the golden scenes).
+// The float64 library calls: sqrt and '/' are correctly rounded on the device (identical to the
+// host on 4M operands each); atan2 / acos / sin come from the device math library and differ from
+// glibc in the last 1-2 bits for 25 % / 6 % / 1.5 % of operands -- but their results are only used
+// through a float32 cast (sphere.uv) or a sign (checker), and a float64 last-bit difference changes
+// the float32 only within ~2^-28 of a rounding boundary: 0 of 4M surface normals give a different
+// float32 (u, v), 0 of 4M (frequency, u) pairs a different checker sign (tools/diag_general.py,
+// profiles/r02_diag_general.txt).  And u, v are used only for the checker sign, so even a float32
+// ulp would matter only where frequency * u crosses an integer.  Frames and final RNG states equal
+// the oracle's on every scene tested (tests allow no differing pixel).
 #pragma once
 
 #include <math.h>
@@ -54,11 +59,17 @@ RF_HD bool sphere_hit(const float *sp, const float o[3], const float d[3], float
         r.n[k] = (r.p[k] - centre[k]) * inv_r;
     }
     r.t = (float)root;
+    return true;
+}
+
+// sphere.py:106-117 uv of the hit that survived world_hit (the reference computes it for every
+// candidate inside hit(); only the closest one's is ever read)
+RF_HD void sphere_texture(const float *sp, HitRec &r)
+{
     r.u = (float)((atan2(-(double)r.n[2], (double)r.n[0]) + kPi) / kPi);
     r.v = (float)(acos(-(double)r.n[1]) / kPi);
     r.fu = sp[4];
     r.fv = sp[5];
-    return true;
 }
 
 RF_HD bool rectangle_hit(const float *rp, const float o[3], const float d[3], float t_min, float t_max, HitRec &r)
@@ -77,11 +88,15 @@ RF_HD bool rectangle_hit(const float *rp, const float o[3], const float d[3], fl
     r.n[1] = 0.0f;
     r.n[2] = 1.0f;
     r.t = t;
-    r.u = (p[0] - rp[0]) / (rp[1] - rp[0]);
-    r.v = (p[1] - rp[2]) / (rp[3] - rp[2]);
+    return true;
+}
+
+RF_HD void rectangle_texture(const float *rp, HitRec &r)
+{
+    r.u = (r.p[0] - rp[0]) / (rp[1] - rp[0]);
+    r.v = (r.p[1] - rp[2]) / (rp[3] - rp[2]);
     r.fu = rp[5];
     r.fv = rp[6];
-    return true;
 }
 
 // sign of sin((f * pi) * u) as the reference evaluates it in float64: -1, 0, +1 (NaN -> 0)
@@ -104,7 +119,7 @@ RF_HD int checker_sign_general(float f, float u)
 RF_HD bool world_hit(const float *params, const int32_t *types, int n_shapes, int width, const float o[3],
                      const float d[3], float t_min, float t_max, HitRec &rec)
 {
-    bool any = false;
+    int which = -1;
     float closest = t_max;
     for (int i = 0; i < n_shapes; ++i) {
         HitRec tmp;
@@ -112,12 +127,18 @@ RF_HD bool world_hit(const float *params, const int32_t *types, int n_shapes, in
         const bool h = types[i] == 0 ? sphere_hit(p, o, d, t_min, closest, tmp)
                                      : rectangle_hit(p, o, d, t_min, closest, tmp);
         if (h) {
-            any = true;
+            which = i;
             closest = tmp.t;
             rec = tmp;
         }
     }
-    return any;
+    if (which < 0)
+        return false;
+    if (types[which] == 0)
+        sphere_texture(params + (long)which * width, rec);
+    else
+        rectangle_texture(params + (long)which * width, rec);
+    return true;
 }
 
 RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes, int width, const float o_in[3],
@@ -141,12 +162,13 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
             ag = ag * (red ? 0.0f : 1.0f);
             ab = ab * 0.0f;
         } else {
-            const double T = sky_t(unit_dir_y(d[0], d[1], d[2]));
-            const float white = (float)(1.0 - T);
+            // physics.py:137-145 in the float32 form proven equal to the float64 chain (rf_math.h)
+            const float ud1 = unit_dir_y(d[0], d[1], d[2]);
+            const float white = sky_white(ud1);
             Colour c;
-            c.r = sky_channel_literal(T, white, 0.5f) * ar;
-            c.g = sky_channel_literal(T, white, 0.7f) * ag;
-            c.b = sky_channel_literal(T, white, 1.0f) * ab;
+            c.r = add2(white, sky_blue(ud1, kSkyHalf[0])) * ar;
+            c.g = add2(white, sky_blue(ud1, kSkyHalf[1])) * ag;
+            c.b = add2(white, sky_blue(ud1, kSkyHalf[2])) * ab;
             return c;
         }
     }
@@ -163,9 +185,15 @@ RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, con
     CamStatic cs{(float)cam[9],  (float)cam[10], (float)cam[11], (float)cam[12], (float)cam[13],
                  (float)cam[14], (float)cam[15], (float)cam[16], (float)cam[17], cam[18], 0.0f, 0.0f, 0};
     cr = cg = cb = 0.0f;
+    // RN32(RN64(x + xi) / w) by the 3-operation quotient of rf_math.h for the frame sizes it is
+    // proven for (every w <= 4096, tests/test_hostsim.py), by the IEEE division otherwise
+    const bool quick = w <= 4096 && h <= 4096;
+    const double w64 = (double)w, h64 = (double)h, rw64 = 1.0 / w64, rh64 = 1.0 / h64;
     for (int k = 0; k < spp; ++k) {
-        const float s = pixel_coord_literal(x, rng_uniform(g), w);
-        const float t = pixel_coord_literal(y, rng_uniform(g), h);
+        const float xi = rng_uniform(g);
+        const float s = quick ? pixel_coord_div(x, xi, w64, rw64) : pixel_coord_literal(x, xi, w);
+        const float yi = rng_uniform(g);
+        const float t = quick ? pixel_coord_div(y, yi, h64, rh64) : pixel_coord_literal(y, yi, h);
         float p0, p1;
         disc_sample(g, p0, p1);
         const double rd0 = (double)p0 * cs.lens_radius, rd1 = (double)p1 * cs.lens_radius;

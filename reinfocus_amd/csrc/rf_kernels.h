@@ -371,23 +371,43 @@ struct GeneralArgs {
 
 __global__ __launch_bounds__(kBlock) void render_general_kernel(GeneralArgs a)
 {
+    __shared__ uint32_t stage[kBlock * 3 / 4]; // the block's 256 pixels x 3 B, stored as 192 coalesced dwords
     const int e = blockIdx.y;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= a.hw)
-        return;
-    const int y = p / a.w, x = p - y * a.w;
-    const size_t pix = (size_t)e * a.hw + p;
-    const ulonglong2 st = a.states[pix];
-    Rng g = rng_load(st.x, st.y);
-    float cr, cg, cb;
-    render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras + (size_t)e * 19,
-                         a.params + ((size_t)e * a.most) * a.width, a.types + (size_t)e * a.most, a.sizes[e],
-                         a.width, cr, cg, cb);
-    a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
-    uint8_t *dst = a.frames + pix * 3;
-    dst[0] = (uint8_t)(cr * a.scale);
-    dst[1] = (uint8_t)(cg * a.scale);
-    dst[2] = (uint8_t)(cb * a.scale);
+    const int p0 = blockIdx.x * kBlock;
+    const int p = p0 + threadIdx.x;
+    const bool live = p < a.hw;
+    const size_t pix = (size_t)e * a.hw + (live ? p : 0);
+    uint8_t r8 = 0, g8 = 0, b8 = 0;
+    if (live) {
+        const int y = p / a.w, x = p - y * a.w;
+        const ulonglong2 st = a.states[pix];
+        Rng g = rng_load(st.x, st.y);
+        float cr, cg, cb;
+        render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras + (size_t)e * 19,
+                             a.params + ((size_t)e * a.most) * a.width, a.types + (size_t)e * a.most, a.sizes[e],
+                             a.width, cr, cg, cb);
+        a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
+        r8 = (uint8_t)(cr * a.scale);
+        g8 = (uint8_t)(cg * a.scale);
+        b8 = (uint8_t)(cb * a.scale);
+    }
+    // a full block whose first byte is dword-aligned goes through LDS; anything else stores bytes
+    const size_t first_byte = ((size_t)e * a.hw + p0) * 3;
+    const bool staged = p0 + kBlock <= a.hw && (first_byte & 3) == 0; // block-uniform
+    if (staged) {
+        uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+        sb[threadIdx.x * 3 + 0] = r8;
+        sb[threadIdx.x * 3 + 1] = g8;
+        sb[threadIdx.x * 3 + 2] = b8;
+        __syncthreads();
+        if (threadIdx.x < kBlock * 3 / 4)
+            reinterpret_cast<uint32_t *>(a.frames + first_byte)[threadIdx.x] = stage[threadIdx.x];
+    } else if (live) {
+        uint8_t *dst = a.frames + pix * 3;
+        dst[0] = r8;
+        dst[1] = g8;
+        dst[2] = b8;
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -208,3 +208,26 @@ def test_render_average_colours(oracle):
     st = oracle.seed_states(300 * 300, 0)
     avg = np.average(oracle.render_general(cams, p, t, s, 300, 300, 100, st, n_threads=8), axis=(0, 1, 2))
     assert np.all(avg >= np.multiply([0.4, 0.4, 0.1], 255)) and np.all(avg <= np.multiply([0.6, 0.6, 0.2], 255))
+
+
+def test_checker_shortcut_equals_the_literal_sine_sign():
+    """rf_general.h checker_sign_general (parity of floor(f * u) away from the checker's edges, the
+    real sin next to them) against the reference's expression sin((f * pi) * u) (physics.py:58-62)
+    with glibc's sin, on random coordinates and on coordinates at / next to every edge."""
+    import subprocess
+
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
+    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    n = 2_000_000
+    rng = np.random.default_rng(3)
+    f = rng.integers(1, 41, n).astype(np.float32)
+    edge = (rng.integers(0, 81, n).astype(np.float32) / f).astype(np.float32)
+    near = np.maximum(edge.view(np.int32) + rng.integers(-3, 4, n).astype(np.int32), 0).view(np.float32)
+    u = np.ascontiguousarray(np.where(rng.random(n) < 0.5, rng.uniform(0, 2, n).astype(np.float32), near))
+    literal = np.zeros(n, dtype=np.int32)
+    own = np.zeros(n, dtype=np.int32)
+    hs.hs_probe_checker_literal(ptr(f), ptr(u), ptr(literal), ctypes.c_uint64(n))
+    hs.hs_probe_checker(ptr(f), ptr(u), ptr(own), ctypes.c_uint64(n))
+    assert np.array_equal(literal, own)
+    assert (literal == 0).sum() > 0 and (literal == 1).sum() > n // 4 and (literal == -1).sum() > n // 4
