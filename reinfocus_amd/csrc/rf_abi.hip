@@ -778,7 +778,10 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     rc = ensure_frames(ctx, n, h, w);
     if (rc != RF_OK)
         return rc;
-    const size_t b_cam = (size_t)n * 19 * sizeof(double), b_par = (size_t)n * most * width * sizeof(float),
+    std::vector<rf::GeneralCamera> cams((size_t)n);
+    for (int e = 0; e < n; ++e)
+        cams[(size_t)e] = rf::general_camera(cameras + (size_t)e * 19);
+    const size_t b_cam = (size_t)n * sizeof(rf::GeneralCamera), b_par = (size_t)n * most * width * sizeof(float),
                  b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t);
     const size_t o_par = (b_cam + 255) & ~(size_t)255, o_typ = o_par + ((b_par + 255) & ~(size_t)255),
                  o_siz = o_typ + ((b_typ + 255) & ~(size_t)255), total = o_siz + b_siz;
@@ -792,7 +795,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
         ctx->general_scratch_bytes = total;
     }
     char *const scratch = (char *)ctx->general_scratch;
-    hipError_t he = hipMemcpyAsync(scratch, cameras, b_cam, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t he = hipMemcpyAsync(scratch, cams.data(), b_cam, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_typ, types, b_typ, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_siz, sizes, b_siz, hipMemcpyHostToDevice, ctx->stream);
@@ -800,7 +803,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
         rf::GeneralArgs a;
         a.frames = ctx->d_frames;
         a.states = ctx->d_states;
-        a.cameras = (const double *)scratch;
+        a.cameras = (const rf::GeneralCamera *)scratch;
         a.params = (const float *)(scratch + o_par);
         a.types = (const int32_t *)(scratch + o_typ);
         a.sizes = (const int32_t *)(scratch + o_siz);
@@ -819,7 +822,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             rf::GeneralArgs b = a;
             b.frames = a.frames + (size_t)e0 * a.hw * 3;
             b.states = a.states + (size_t)e0 * a.hw;
-            b.cameras = a.cameras + (size_t)e0 * 19;
+            b.cameras = a.cameras + (size_t)e0;
             b.params = a.params + (size_t)e0 * most * width;
             b.types = a.types + (size_t)e0 * most;
             b.sizes = a.sizes + e0;

@@ -64,10 +64,34 @@ RF_HD bool sphere_hit(const float *sp, const float o[3], const float d[3], float
 
 // sphere.py:106-117 uv of the hit that survived world_hit (the reference computes it for every
 // candidate inside hit(); only the closest one's is ever read)
+// The float64 library calls (atan2, acos, sin) expand to long instruction sequences with many
+// live registers; inlined into the bounce loop they push the kernel to ~200 VGPRs (2 waves per
+// SIMD).  Kept out of line, with arguments and results in registers, the kernel needs ~110.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_COLD __device__ __attribute__((noinline))
+#else
+#define RF_COLD inline
+#endif
+struct TexCoord {
+    float u, v;
+};
+
+// sphere.py:106-117 uv from the surface normal
+RF_COLD TexCoord sphere_uv(float n0, float n1, float n2)
+{
+    TexCoord t;
+    t.u = (float)((atan2(-(double)n2, (double)n0) + kPi) / kPi);
+    t.v = (float)(acos(-(double)n1) / kPi);
+    return t;
+}
+
+// uv of the hit that survived world_hit (the reference computes it for every candidate inside
+// hit(); only the closest one's is ever read)
 RF_HD void sphere_texture(const float *sp, HitRec &r)
 {
-    r.u = (float)((atan2(-(double)r.n[2], (double)r.n[0]) + kPi) / kPi);
-    r.v = (float)(acos(-(double)r.n[1]) / kPi);
+    const TexCoord t = sphere_uv(r.n[0], r.n[1], r.n[2]);
+    r.u = t.u;
+    r.v = t.v;
     r.fu = sp[4];
     r.fv = sp[5];
 }
@@ -100,7 +124,7 @@ RF_HD void rectangle_texture(const float *rp, HitRec &r)
 }
 
 // sign of sin((f * pi) * u) as the reference evaluates it in float64: -1, 0, +1 (NaN -> 0)
-RF_HD int checker_sign_general(float f, float u)
+RF_COLD int checker_sign_general(float f, float u)
 {
     const double m = (double)f * (double)u; // exact: two f32 factors
     if (!(m == m) || m - m != 0.0)          // NaN or infinite argument: sin is NaN
@@ -175,18 +199,35 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
     return Colour{0.0f, 0.0f, 0.0f};
 }
 
+// camera.from_cameras (camera.py:255-281): the float64[19] row of camera.Cameras cast to the
+// float32 tuples the kernel works with (lens radius stays float64).  The casts are per
+// environment, not per pixel: the GPU path does them once on the host (rf_abi.hip) so that the
+// kernel reads block-uniform floats into scalar registers.
+struct GeneralCamera {
+    float f[18]; // lower_left, horizontal, vertical, origin, u, v
+    double lens_radius;
+};
+
+RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
+{
+    GeneralCamera c;
+    for (int k = 0; k < 18; ++k)
+        c.f[k] = (float)cam[k];
+    c.lens_radius = cam[18];
+    return c;
+}
+
 // one pixel of device_render
-RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, const double *cam /*[19]*/,
+RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, const GeneralCamera &cam,
                                 const float *params, const int32_t *types, int n_shapes, int width, float &cr,
                                 float &cg, float &cb)
 {
-    CamDyn dyn{(float)cam[0], (float)cam[1], (float)cam[2], (float)cam[3], (float)cam[4],
-               (float)cam[5], (float)cam[6], (float)cam[7], (float)cam[8]};
-    CamStatic cs{(float)cam[9],  (float)cam[10], (float)cam[11], (float)cam[12], (float)cam[13],
-                 (float)cam[14], (float)cam[15], (float)cam[16], (float)cam[17], cam[18], 0.0f, 0.0f, 0};
+    const CamDyn dyn{cam.f[0], cam.f[1], cam.f[2], cam.f[3], cam.f[4], cam.f[5], cam.f[6], cam.f[7], cam.f[8]};
+    const CamStatic cs{cam.f[9],  cam.f[10], cam.f[11], cam.f[12], cam.f[13],
+                       cam.f[14], cam.f[15], cam.f[16], cam.f[17], cam.lens_radius, 0.0f, 0.0f, 0};
     cr = cg = cb = 0.0f;
     // RN32(RN64(x + xi) / w) by the 3-operation quotient of rf_math.h for the frame sizes it is
-    // proven for (every w <= 4096, tests/test_hostsim.py), by the IEEE division otherwise
+    // proven for (every w <= 4096, see pixel_coord_div), by the IEEE division otherwise
     const bool quick = w <= 4096 && h <= 4096;
     const double w64 = (double)w, h64 = (double)h, rw64 = 1.0 / w64, rh64 = 1.0 / h64;
     for (int k = 0; k < spp; ++k) {

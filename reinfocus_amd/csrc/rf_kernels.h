@@ -355,13 +355,16 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
 
 // ---------------------------------------------------------------------------
 // render_general_kernel: device_render (graphics/render.py:31-85) for worlds of spheres and
-// rectangles with per-environment cameras; literal arithmetic (rf_general.h), one thread
-// per pixel, lanes along x.  Not the benchmarked path: no specialisations.
+// rectangles with per-environment cameras; arithmetic in rf_general.h, one thread per pixel,
+// lanes along x, frame bytes staged through LDS.  Held to 5 waves per SIMD: with the float64
+// library calls inlined the kernel needed 208 VGPRs (2 waves per SIMD, 42.5 G samples/s on
+// one-rectangle scenes); with them out of line 112 (4 waves: 55.6), and at 96 registers with six
+// spilled (5 waves) 58.0 -- tools/bench_general.py, profiles/README.md.
 // ---------------------------------------------------------------------------
 struct GeneralArgs {
     uint8_t *frames;
     ulonglong2 *states;
-    const double *cameras;  // [n][19]
+    const GeneralCamera *cameras; // [n], cast from float64[n][19] on the host
     const float *params;    // [n][most][width]
     const int32_t *types;   // [n][most]
     const int32_t *sizes;   // [n]
@@ -369,7 +372,7 @@ struct GeneralArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(kBlock) void render_general_kernel(GeneralArgs a)
+__global__ __launch_bounds__(kBlock, 5) void render_general_kernel(GeneralArgs a)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4]; // the block's 256 pixels x 3 B, stored as 192 coalesced dwords
     const int e = blockIdx.y;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void render_general_kernel(GeneralArgs a)
         const ulonglong2 st = a.states[pix];
         Rng g = rng_load(st.x, st.y);
         float cr, cg, cb;
-        render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras + (size_t)e * 19,
+        render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras[e],
                              a.params + ((size_t)e * a.most) * a.width, a.types + (size_t)e * a.most, a.sizes[e],
                              a.width, cr, cg, cb);
         a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));

@@ -74,7 +74,7 @@ int hs_render_general(uint8_t *frames, int n, int h, int w, int spp, const doubl
                 const long pix = ((long)e * h + y) * w + x;
                 Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
                 float cr, cg, cb;
-                render_pixel_general(g, x, y, h, w, spp, cameras + (long)e * 19, params + ((long)e * most) * width,
+                render_pixel_general(g, x, y, h, w, spp, general_camera(cameras + (long)e * 19), params + ((long)e * most) * width,
                                      types + (long)e * most, sizes[e], width, cr, cg, cb);
                 states[2 * pix] = rng_s0(g);
                 states[2 * pix + 1] = rng_s1(g);
