@@ -14,6 +14,7 @@ import numpy as np
 
 from reinfocus_amd import _native
 from reinfocus_amd.graphics import camera
+from reinfocus_amd.graphics import cutil
 from reinfocus_amd.graphics import world
 
 
@@ -76,7 +77,7 @@ class FastRenderer:
         """block_shape is accepted for signature parity; the gfx950 kernel fixes its own
         launch geometry (256-thread blocks, lanes along x).  `device` / `first_state_index`
         are extensions for one-process-per-GPU sharding (default: LOCAL_RANK, 0)."""
-        self._block_shape = block_shape
+        self._block_shape = cutil.check_block_shape(block_shape)
         self._samples_per_pixel = samples_per_pixel
         self._cameras = camera.FastCameras()
         self._worlds = world.FastWorlds(r_size=r_size)
@@ -138,7 +139,9 @@ def render(world_data, cameras, frame_shape=(300, 600), block_shape=(1, 16, 16),
            device=None):
     """render.render (render.py:88-119): ray traced images uint8[N, H, W, 3] of world_data
     (world.Worlds) seen by cameras (camera.Cameras); fresh seed-0 RNG states per call, up
-    to 50 bounces per sample.  block_shape is accepted for signature parity."""
+    to 50 bounces per sample.  block_shape is checked as the reference's launcher would
+    (cutil.check_block_shape); the gfx950 kernel fixes its own launch geometry."""
+    cutil.check_block_shape(block_shape)
     parameters, types, sizes = world_data.device_data()
     ctx = _native.Context(device)
     try:

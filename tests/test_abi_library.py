@@ -63,3 +63,17 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
                 assert "librf_oracle" not in text and "rf_oracle.h" not in text, os.path.join(dirpath, f)
                 assert "hostsim" not in text or f == "rf_math.h", os.path.join(dirpath, f)
+
+
+def test_built_libraries_are_not_older_than_their_sources():
+    """The .so files are git-ignored but travel to the GPU box: a stale one would be tested there in
+    place of what the checkout builds.  `make -q` says whether a rebuild is due (the Makefiles list
+    every header)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for directory, target in (("reinfocus_amd/csrc", "all"), ("tests/gpucheck", "all"), ("tests/hostsim", "libhostsim.so"),
+                              ("oracle", "librf_oracle.so")):
+        rc = subprocess.call(["make", "-q", "-C", os.path.join(root, directory), target],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert rc == 0, f"{directory}: {target} is out of date -- run __graft_entry__.build()"

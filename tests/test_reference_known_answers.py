@@ -5,6 +5,7 @@ kernels replaced by direct calls of the oracle's device functions.  The last tes
 the oracle to real outputs of the reference itself (examples/environment.ipynb)."""
 
 import numpy as np
+import pytest
 from numpy import testing
 
 from tests import helpers
@@ -264,3 +265,33 @@ def test_oracle_reproduces_reference_notebook(oracle):
     assert repr(obs1) == "array([ 0.59203607, -0.873161  ,  0.0625    , -0.01416067], dtype=float32)"
     reward = (abs(focus1 - focus0) * -1.0 / 0.5 + obs1[1]) + ((abs(target - focus1) < 0.25) * 1.0 + 0.0)
     assert reward == -1.4981610774993896
+
+
+def test_cutil_known_answers():
+    """tests/graphics/cutil_test.py:13-65 of the reference: enough_blocks, constant_like,
+    limit_block_size; plus the launch the reference's FastRenderer would make (render.py:174-180)."""
+    from reinfocus_amd.graphics import cutil
+
+    line_blocks = cutil.enough_blocks(100, 8)
+    assert isinstance(line_blocks, int) and line_blocks == 13
+    assert cutil.enough_blocks((10, 20), (2, 8)) == (5, 3)
+    assert cutil.enough_blocks((9, 27, 54), (2, 5, 10)) == (5, 6, 6)
+    assert cutil.constant_like(0, 1) == 0
+    assert cutil.constant_like(0, (1, 1)) == (0, 0)
+    assert cutil.constant_like(0, (1, 1, 1)) == (0, 0, 0)
+    assert cutil.constant_like(4, 20) == 4
+    assert cutil.constant_like(20, (1, 10)) == (1, 10)
+    assert cutil.constant_like(9, (1, 3, 9)) == (1, 3, 9)
+    assert cutil.limit_block_size(10000) <= cutil.MAX_BLOCK_SIZE == 1024
+    assert np.prod(cutil.limit_block_size((64, 64))) <= 1024
+    assert np.prod(cutil.limit_block_size((16, 16, 16))) <= 1024
+    assert cutil.limit_block_size((16, 16, 16)) == (8, 8, 16)  # the largest side is halved first
+    # FastRenderer's launch in the reference: grid (N, h, h), block (1, 16, 16)
+    assert cutil.launch_shapes((4096, 256, 256), (1, 16, 16)) == ((4096, 16, 16), (1, 16, 16))
+    assert cutil.launch_shapes((13, 300, 300), (1, 16, 16)) == ((13, 19, 19), (1, 16, 16))
+    assert cutil.launch_shapes((2, 5, 40)) == ((1, 1, 3), (2, 5, 16))
+    assert cutil.check_block_shape((1, 16, 16)) == (1, 16, 16)
+    assert cutil.check_block_shape((4, 32, 32)) == (4, 16, 16)
+    for bad in ((16, 16), (1, 0, 16), (1, -2, 16)):
+        with pytest.raises(AssertionError):
+            cutil.check_block_shape(bad)
