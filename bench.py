@@ -158,6 +158,14 @@ class Ranks:
 # ---------------------------------------------------------------------------------------------
 # figures taken from the committed rocprofv3 PMC summary (profiles/<tag>_pmc.json)
 # ---------------------------------------------------------------------------------------------
+def kernel_key(name):
+    """'void rf::render_kernel_coop2<true, 1, 4, 32>(rf::RenderArgs)' -> 'render_kernel_coop2<true,1,4,32>'."""
+    name = name.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    return name.replace("rf::", "").replace(" ", "")
+
+
 def committed_profile(kernel, frame, spp):
     """The newest committed PMC summary (by round tag) that was collected for exactly this kernel
     instance at this frame size and sample count, or (None, reason).  These figures are NOT measured
@@ -174,7 +182,7 @@ def committed_profile(kernel, frame, spp):
         if not config or config.get("frame") != frame or config.get("spp") != spp:
             continue
         for name, entry in data.items():
-            if name.replace("rf::", "").replace(" ", "") == kernel.replace(" ", "") and entry.get("SQ_WAVES"):
+            if kernel_key(name) == kernel_key(kernel) and entry.get("SQ_WAVES"):
                 return {"file": os.path.basename(path), "commit": meta.get("commit"), "config": config,
                         "entry": entry}, None
     return None, f"no committed PMC summary for {kernel} at frame {frame} / spp {spp}"

@@ -87,3 +87,25 @@ def test_parent_launcher_never_loads_the_hip_library():
     assert native_lines and launch_line < min(native_lines)
     top_level = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
     assert not any("reinfocus_amd" in ast.dump(n) or "torch" in ast.dump(n) for n in top_level)
+
+
+def test_committed_profile_is_matched_by_kernel_and_configuration():
+    """roofline.traffic / roofline_valu come from the committed PMC summary of exactly the kernel
+    instance, frame size and sample count of the run -- and from nothing else."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.kernel_key("void rf::render_kernel_coop2<true, 1, 4, 32>(rf::RenderArgs)") == \
+        bench.kernel_key("render_kernel_coop2<true, 1, 4, 32>") == "render_kernel_coop2<true,1,4,32>"
+    profile, why_not = bench.committed_profile("render_kernel_coop2<true, 1, 4, 32>", 256, 16)
+    assert profile is not None, why_not
+    assert profile["config"]["frame"] == 256 and profile["config"]["spp"] == 16 and profile["commit"]
+    traffic, valu = bench.roofline_from_profile(profile, 4096 * 65536)
+    assert 0.9 < traffic / (35 * 4096 * 65536) < 1.1          # HBM traffic ~ the algorithmic bytes
+    assert valu["from_committed_profile"] is True and 0.3 < valu["frac"] < 1.0
+    assert 0 < valu["barrier_wait_share"] < 1 and 0 < valu["salu_per_valu"] < 1
+    # another kernel instance, or another configuration: no figures rather than wrong ones
+    assert bench.committed_profile("render_kernel_coop2<true, 0, 4, 32>", 256, 16)[0] is None
+    assert bench.committed_profile("render_kernel_coop2<true, 1, 4, 32>", 256, 32)[0] is None
+    ref300, _ = bench.committed_profile("render_kernel_coop2<false, 1, 2, 32>", 300, 100)
+    assert ref300 is not None and ref300["file"].startswith("r02_ref300")
