@@ -69,6 +69,22 @@ static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in Coo
 #endif
 constexpr int kTileH2 = kTileH * kSets;
 
+// A 32-bit value nobody has to compute: the raw-draw words of a sample are written by the first
+// attempt of every lane that will ever read them (disc: every live lane; sphere: every lane that
+// hit), so their initial value is irrelevant -- but it has to be *some* value for the compiler.
+// An empty asm with an output gives it one without an instruction (zeroing 18 words per
+// iteration was 2 % of the kernel's VALU instructions).
+__device__ __forceinline__ uint32_t any_u32();
+#ifndef RF_WORD_INIT
+#define RF_WORD_INIT any_u32()
+#endif
+__device__ __forceinline__ uint32_t any_u32()
+{
+    uint32_t v;
+    asm("" : "=v"(v));
+    return v;
+}
+
 // coop_finish for kSets pixel sets at once.  The packed list holds kCoopCap entries (the LDS
 // arrays of CoopLds); stragglers that do not fit finish their loop in their own wave.  Returns
 // the number of stragglers the block had (block-uniform).
@@ -320,11 +336,11 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         bool need[kSets];
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                w[j][i] = 0;
             sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h64, a.w64, a.inv_w, a.inv_h,
                                 a.rw64, a.rh64, s[j], t[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                w[j][i] = RF_WORD_INIT;
             need[j] = gk.live_of(j);
             if (need[j] && disc_attempt(g[j], w[j]))
                 need[j] = false;
@@ -337,6 +353,8 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             float p0, p1;
             disc_finish(w[j], p0, p1);
             pre[j] = sample_axis_ray<LENS>(p0, p1, env, a.cs, s[j], t[j], a.tab);
+            w[j][4] = RF_WORD_INIT;
+            w[j][5] = RF_WORD_INIT;
             need[j] = gk.live_of(j) && pre[j].hit;
 #pragma unroll
             for (int trip = 0; trip < kCoopTrips2 + 1; ++trip) {
@@ -365,15 +383,16 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             const Colour c = sample_axis_shade(pre[j], q0, q1, q2);
 #if RF_COLOUR_LDS > 0
             if (j < RF_COLOUR_LDS) {
-                lds_colour[j][0][tid] = add2(lds_colour[j][0][tid], c.r);
-                lds_colour[j][1][tid] = add2(lds_colour[j][1][tid], c.g);
-                lds_colour[j][2][tid] = add2(lds_colour[j][2][tid], c.b);
+                // (the sums and every sample colour are >= +0, never -0: see add2_not_negzero)
+                lds_colour[j][0][tid] = add2_not_negzero(lds_colour[j][0][tid], c.r);
+                lds_colour[j][1][tid] = add2_not_negzero(lds_colour[j][1][tid], c.g);
+                lds_colour[j][2][tid] = add2_not_negzero(lds_colour[j][2][tid], c.b);
                 continue;
             }
 #endif
-            cr[j] = add2(cr[j], c.r);
-            cg[j] = add2(cg[j], c.g);
-            cb[j] = add2(cb[j], c.b);
+            cr[j] = add2_not_negzero(cr[j], c.r);
+            cg[j] = add2_not_negzero(cg[j], c.g);
+            cb[j] = add2_not_negzero(cb[j], c.b);
         }
     }
 #if RF_COLOUR_LDS > 0

@@ -247,6 +247,10 @@ RF_HD bool checker_red(float u, float v, const CheckerTable &tab)
 // Literal/general version: any camera frame.  Returns the sample colour.
 // ---------------------------------------------------------------------------
 RF_HD float add2(float a, float b) { return (0.0f + a) + b; }
+// add2 for a first operand that is never -0 (then 0 + a == a bit for bit, NaN included): the
+// running colour sums (start at +0, only ever grow by terms >= +0) and the sky's white part
+// fma(-0.5, ud, 0.5), whose only zero is the exact 0.5 - 0.5 = +0.
+RF_HD float add2_not_negzero(float a, float b) { return a + b; }
 RF_HD float add3(float a, float b, float c) { return ((0.0f + a) + b) + c; }
 
 RF_HD float sq_len(float a, float b, float c)
@@ -602,14 +606,14 @@ RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
     Colour c;
     if (r.hit) {
         // attenuation (1,0,0) or (0,1,0): the other channels contribute +0
-        float ch = add2(white, sky_blue(ud1, r.red ? kSkyHalf[0] : kSkyHalf[1]));
+        float ch = add2_not_negzero(white, sky_blue(ud1, r.red ? kSkyHalf[0] : kSkyHalf[1]));
         c.r = r.red ? ch : 0.0f;
         c.g = r.red ? 0.0f : ch;
         c.b = 0.0f;
     } else {
-        c.r = add2(white, sky_blue(ud1, kSkyHalf[0]));
-        c.g = add2(white, sky_blue(ud1, kSkyHalf[1]));
-        c.b = add2(white, sky_blue(ud1, kSkyHalf[2]));
+        c.r = add2_not_negzero(white, sky_blue(ud1, kSkyHalf[0]));
+        c.g = add2_not_negzero(white, sky_blue(ud1, kSkyHalf[1]));
+        c.b = add2_not_negzero(white, sky_blue(ud1, kSkyHalf[2]));
     }
     return c;
 }
