@@ -91,10 +91,12 @@ def launch_ranks(world, argv):
                                          stdout=out, cwd=os.getcwd()))
     import threading
 
-    def relay(pipe):
+    def relay(pipe):  # rank 0's JSON line goes to stdout, anything else it printed to stderr
         for line in iter(pipe.readline, b""):
-            sys.stdout.write(line.decode("utf-8", "replace"))
-            sys.stdout.flush()
+            text = line.decode("utf-8", "replace")
+            out = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+            out.write(text)
+            out.flush()
 
     pump = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
     pump.start()
@@ -134,7 +136,18 @@ class Ranks:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            # gloo announces its connections on stdout, which belongs to the one JSON line:
+            # file descriptor 1 points at stderr while the group forms
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.dist = dist
 
     def barrier(self):

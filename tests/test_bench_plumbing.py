@@ -27,8 +27,8 @@ def _run(cmd):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout  # stdout is the JSON line and nothing else
     return json.loads(lines[0])
 
 
@@ -55,8 +55,8 @@ def test_bench_launches_its_own_ranks():
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "4", "--warmup", "1"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout  # stdout is the JSON line and nothing else
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4
     assert line["config"]["total_envs"] == 2 * line["config"]["envs_per_gpu"]
