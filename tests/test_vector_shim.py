@@ -94,3 +94,95 @@ def test_rewrapper_needs_stable_baselines3():
             vector_shim.rewrapper(object())
     else:  # pragma: no cover - not installed in this image
         assert vector_shim.rewrapper("not a DummyVecEnv") == "not a DummyVecEnv"
+
+
+def test_rewrapper_with_stable_baselines3_on_the_path(tmp_path):
+    """vector_shim.rewrapper (reference: experimental/vector_shim.py:187-229) needs stable-baselines3,
+    which this image does not have: a minimal package with SB3's module layout and the classes the
+    function touches (DummyVecEnv, VecEnv, Monitor, VecMonitor) stands in, in a fresh interpreter.
+    Checked: anything but a DummyVecEnv of a registered environment passes through unchanged; a
+    DummyVecEnv of n Monitor-wrapped DiscreteSteps-v0 members becomes VecMonitor(SB3Wrapper(ONE
+    vector environment of n members)) built through the env id's vector entry point with the
+    spec's max_episode_steps and render_mode "human" -> "rgb_array"; SB3Wrapper derives from SB3's
+    VecEnv."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = tmp_path / "stable_baselines3"
+    (pkg / "common" / "vec_env").mkdir(parents=True)
+    (pkg / "__init__.py").write_text("")
+    (pkg / "common" / "__init__.py").write_text("")
+    (pkg / "common" / "monitor.py").write_text(textwrap.dedent("""
+        class Monitor:
+            EXT = "monitor.csv"
+            def __init__(self, env, info_keywords=()):
+                self.env, self.info_keywords = env, info_keywords
+                self.spec, self.render_mode = env.spec, env.render_mode
+        """))
+    (pkg / "common" / "vec_env" / "base_vec_env.py").write_text(textwrap.dedent("""
+        class VecEnv:
+            def __init__(self, num_envs, observation_space, action_space):
+                self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+                self.render_mode = None
+            def step(self, actions):
+                self.step_async(actions)
+                return self.step_wait()
+        """))
+    (pkg / "common" / "vec_env" / "vec_monitor.py").write_text(textwrap.dedent("""
+        class VecMonitor:
+            def __init__(self, venv, filename=None, info_keywords=()):
+                self.venv, self.filename, self.info_keywords = venv, filename, info_keywords
+        """))
+    (pkg / "common" / "vec_env" / "__init__.py").write_text(textwrap.dedent("""
+        from stable_baselines3.common.vec_env.base_vec_env import VecEnv
+        class DummyVecEnv(VecEnv):
+            def __init__(self, envs):
+                self.envs = envs
+                self.num_envs = len(envs)
+        """))
+    code = textwrap.dedent("""
+        import types
+        import numpy as np
+        from stable_baselines3.common import monitor, vec_env
+        from stable_baselines3.common.vec_env import base_vec_env, vec_monitor
+        from reinfocus_amd import registration
+        from reinfocus_amd.environments import vector_shim
+        from tests.test_vector_shim import _Scripted
+
+        assert issubclass(vector_shim.SB3Wrapper, base_vec_env.VecEnv)
+        asked = []
+        def make_vec(env_id, num_envs, **kwargs):
+            asked.append((env_id, num_envs, kwargs))
+            return _Scripted(num_envs)
+        registration.make_vec = make_vec
+
+        not_dummy = object()
+        assert vector_shim.rewrapper(not_dummy) is not_dummy
+        def member(spec, render_mode="human"):
+            return types.SimpleNamespace(spec=spec, render_mode=render_mode)
+        no_spec = vec_env.DummyVecEnv([member(None)])
+        assert vector_shim.rewrapper(no_spec) is no_spec and asked == []
+
+        spec = types.SimpleNamespace(id="DiscreteSteps-v0", max_episode_steps=7)
+        members = [monitor.Monitor(member(spec), info_keywords=("k",)) for _ in range(3)]
+        result = vector_shim.rewrapper(vec_env.DummyVecEnv(members))
+        assert asked == [("DiscreteSteps-v0", 3, {"max_episode_steps": 7, "render_mode": "rgb_array"})]
+        assert isinstance(result, vec_monitor.VecMonitor)
+        assert result.filename == "monitor.csv" and result.info_keywords == ("k",)
+        wrapper = result.venv
+        assert isinstance(wrapper, vector_shim.SB3Wrapper) and wrapper.num_envs == 3 and wrapper.render_mode == "rgb_array"
+        observations, rewards, dones, infos = wrapper.step(np.array([1, 2, 3]))
+        assert observations.shape == (3, 4) and list(dones) == [False, True, True]
+
+        plain = vector_shim.rewrapper(vec_env.DummyVecEnv([member(types.SimpleNamespace(id="DiscreteSteps-v0",
+                                                                                      max_episode_steps=None), None)]))
+        assert isinstance(plain, vector_shim.SB3Wrapper) and plain.render_mode is None
+        assert asked[-1] == ("DiscreteSteps-v0", 1, {"render_mode": None})
+        print("ok")
+        """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), root]), REINFOCUS_NO_AUTOBUILD="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300, cwd=root)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-3000:]
