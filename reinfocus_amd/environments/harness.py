@@ -378,6 +378,7 @@ class _DeviceShard:
     ENDS = (5.0, 10.0)
     TARGET_RADIUS = 0.25
     MAX_MOVE = 5.0
+    EARLY_END_STEPS = 3  # DivergingEnder(..., early_end_steps=3), custom_environments.py:186-190
 
     def __init__(self, num_envs, max_episode_steps, frame_height, samples_per_pixel, device, first_state_index):
         import math
@@ -407,7 +408,7 @@ class _DeviceShard:
             cfg.limit_lo, cfg.limit_hi = self.ENDS
             cfg.max_steps = max_episode_steps if max_episode_steps else 0
             cfg.diverge_threshold = self.TARGET_RADIUS / 2
-            cfg.early_end_steps = 3
+            cfg.early_end_steps = self.EARLY_END_STEPS
             for i in range(4):
                 cfg.mid[i] = float(mid[i])
                 cfg.scale[i] = float(scale[i])
@@ -444,7 +445,7 @@ class _DeviceShard:
     def status(self, index):
         """_Ender.status from the counters on the device."""
         steps, diverging = self.ctx.env_counters()
-        r_status = f"diverging {diverging[index]} / 3" if diverging[index] > 0 else ""
+        r_status = f"diverging {diverging[index]} / {self.EARLY_END_STEPS}" if diverging[index] > 0 else ""
         if not self.max_episode_steps:
             return r_status
         l_status = f"step {steps[index]} / {self.max_episode_steps}"

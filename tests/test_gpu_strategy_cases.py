@@ -318,7 +318,6 @@ def test_observers_on_device(name):
     # end, and take the reference's new values from the pool; the others do not move.
     target = SHIFT + 30.0
     position = np.asarray(ops[0]["values"], dtype=np.float64) + SHIFT
-    dev = None
     action_values = {0.0, -1.0}
     walk = position.copy()
     for op in ops[1:]:
