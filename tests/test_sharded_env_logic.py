@@ -96,7 +96,7 @@ def test_sharded_step_equals_one_shard(fake_shards, n, devices):
     from reinfocus_amd.environments import harness
 
     many = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=devices, frame_height=16, samples_per_pixel=1, seed=4)
-    shards = [s for s in fake_shards]
+    shards = sorted(fake_shards, key=lambda s: s.first_env)  # built on the pool's threads, in any order
     assert [s.device for s in shards] == devices
     assert [(s.first_env, s.num_envs) for s in shards] == harness.split_environments(n, len(devices))
     one = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=[0], frame_height=16, samples_per_pixel=1, seed=4)
