@@ -57,6 +57,10 @@ def parse_args(argv=None):
                     help="one process: harness.ShardedVectorDiscreteSteps over --gpus devices (threads), instead "
                          "of one process per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic and roofline_valu in this invocation: after the timed run, "
+                         "four short child runs of this script under rocprofv3 --pmc (counters only, one group "
+                         "per run) instead of the committed profile's figures; adds about a minute")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="no per-kernel HIP events (and no roofline object): lets small configurations replay "
                          "their step as one hipGraph")
@@ -223,10 +227,84 @@ def roofline_from_profile(profile, pixels_per_launch):
             "inst_wait_share": e.get("inst_wait_share"),      # SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
             "salu_per_valu": e.get("salu_per_valu"),          # SQ_INSTS_SALU / SQ_INSTS_VALU
             "valu_insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / float(e.get("pixels_per_wave", 64)),
-            "from_committed_profile": True,
+            "from_committed_profile": profile["file"] is not None,
+            "measured_by": ("profiles/" + profile["file"] if profile["file"] else
+                            "rocprofv3 --pmc child runs of this invocation (bench.py --pmc)"),
             "profile": {k: profile[k] for k in ("file", "commit", "config")},
         }
     return traffic, valu
+
+
+PMC_GROUPS = (
+    "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY",
+    "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE GRBM_COUNT",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
+)
+
+
+def derive_pmc(e, kernel):
+    """Derived figures of one kernel's PMC totals (the same definitions as profiles/summarize.py)."""
+    e = dict(e)
+    if "FETCH_SIZE" in e:
+        e["hbm_read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2  # KiB; gfx950 counts wide reads at half
+    if "WRITE_SIZE" in e:
+        e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+    e["pixels_per_wave"] = 192 if "render_kernel_coop2" in kernel else 64
+    if e.get("SQ_WAVES") and "SQ_INSTS_VALU" in e:
+        e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+    if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_INSTS_VALU"):
+        e["valu_insts_per_cycle_per_simd"] = e["SQ_INSTS_VALU"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if e.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in e:
+        e["valu_lane_utilisation"] = e["SQ_THREAD_CYCLES_VALU"] / (e["SQ_ACTIVE_INST_VALU"] * 64)
+    if e.get("SQ_WAVE_CYCLES"):
+        if "SQ_WAIT_ANY" in e:
+            e["wait_share"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+        if "SQ_WAIT_INST_ANY" in e:
+            e["inst_wait_share"] = e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]
+    if e.get("SQ_INSTS_VALU") and "SQ_INSTS_SALU" in e:
+        e["salu_per_valu"] = e["SQ_INSTS_SALU"] / e["SQ_INSTS_VALU"]
+    return e
+
+
+def measure_pmc(args, kernel):
+    """Counter totals of `kernel` from child runs of this script under rocprofv3 --pmc (one counter
+    group per run, never combined with a tracing domain, program directly after `--`), as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Returns a profile dict like
+    committed_profile()'s, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="reinfocus_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+             "--envs-per-gpu", str(args.envs_per_gpu), "--frame", str(args.frame), "--spp", str(args.spp),
+             "--env", args.env]
+    totals = {}
+    try:
+        for index, group in enumerate(PMC_GROUPS):
+            out = os.path.join(work, f"pass{index}")
+            cmd = [rocprof, "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--", *child]
+            done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                                  timeout=600)
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if done.returncode != 0 or not files:
+                return None, f"rocprofv3 pass {index} failed (rc {done.returncode}): {done.stderr[-300:]}"
+            for row in csv.DictReader(open(files[0])):
+                if kernel_key(row["Kernel_Name"]) == kernel_key(kernel):
+                    totals[row["Counter_Name"]] = totals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        if not totals.get("SQ_WAVES"):
+            return None, f"no counters for {kernel}"
+        return {"file": None, "commit": None, "entry": derive_pmc(totals, kernel),
+                "config": {"envs": args.envs_per_gpu, "frame": args.frame, "spp": args.spp, "kernel": kernel}}, None
+    except (OSError, subprocess.TimeoutExpired) as error:
+        return None, f"rocprofv3: {error}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def shard_plan(rank, envs_per_gpu, frame):
@@ -432,8 +510,13 @@ def main(argv=None):
             achieved = RENDER_BYTES_PER_PIXEL * pixels / render_s / 1e9
             launches = max(timing["render_launches"], 1)
             kernel = ctx.render_kernel_name()
-            profile, why_not = committed_profile(kernel, frame, spp)
+            profile, why_not, pmc_failure = None, None, None
+            if args.pmc and n_gpus == 1:
+                profile, pmc_failure = measure_pmc(args, kernel)
+            if profile is None:
+                profile, why_not = committed_profile(kernel, frame, spp)
             traffic, valu = roofline_from_profile(profile, pixels / launches) if profile else (None, None)
+            live = profile is not None and profile["file"] is None
             out["roofline"] = {
                 "bound": "hbm",
                 "kernel": kernel,
@@ -449,13 +532,17 @@ def main(argv=None):
                 "samples_per_s": pixels * spp / render_s,
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                "traffic_from_committed_profile": traffic is not None,
+                "traffic_from_committed_profile": traffic is not None and not live,
+                "traffic_measured_by": ("rocprofv3 --pmc child runs of this invocation (bench.py --pmc)" if live else
+                                        "committed profile" if traffic is not None else None),
                 "traffic_profile": ({k: profile[k] for k in ("file", "commit", "config")} if profile
                                     else {"unavailable": why_not}),
                 "note": "HBM is the nominated roof; the kernel is bound by VALU issue (64-bit xoroshiro128+ "
                         "draws and rejection loops fixed by parity): see roofline_valu and DESIGN.md",
             }
             out["roofline_valu"] = valu if valu is not None else {"unavailable": why_not, "from_committed_profile": True}
+            if pmc_failure:
+                out["roofline"]["pmc_failure"] = pmc_failure
             out["focus_kernel"] = {
                 "achieved_GBps": FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9,
                 "avg_launch_ms": timing["focus_ms"] / max(timing["focus_launches"], 1),
