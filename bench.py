@@ -57,10 +57,10 @@ def parse_args(argv=None):
                     help="one process: harness.ShardedVectorDiscreteSteps over --gpus devices (threads), instead "
                          "of one process per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc", action="store_true",
-                    help="measure roofline.traffic and roofline_valu in this invocation: after the timed run, "
-                         "four short child runs of this script under rocprofv3 --pmc (counters only, one group "
-                         "per run) instead of the committed profile's figures; adds about a minute")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="take roofline.traffic and roofline_valu from the committed profile instead of measuring "
+                         "them in this invocation (by default, at N = 1: four short child runs of this script under "
+                         "rocprofv3 --pmc after the timed run -- counters only, one group per run; about a minute)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="no per-kernel HIP events (and no roofline object): lets small configurations replay "
                          "their step as one hipGraph")
@@ -229,7 +229,7 @@ def roofline_from_profile(profile, pixels_per_launch):
             "valu_insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / float(e.get("pixels_per_wave", 64)),
             "from_committed_profile": profile["file"] is not None,
             "measured_by": ("profiles/" + profile["file"] if profile["file"] else
-                            "rocprofv3 --pmc child runs of this invocation (bench.py --pmc)"),
+                            "rocprofv3 --pmc child runs of this invocation"),
             "profile": {k: profile[k] for k in ("file", "commit", "config")},
         }
     return traffic, valu
@@ -281,7 +281,7 @@ def measure_pmc(args, kernel):
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
     work = tempfile.mkdtemp(prefix="reinfocus_pmc_", dir="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc",
              "--envs-per-gpu", str(args.envs_per_gpu), "--frame", str(args.frame), "--spp", str(args.spp),
              "--env", args.env]
     totals = {}
@@ -290,7 +290,7 @@ def measure_pmc(args, kernel):
             out = os.path.join(work, f"pass{index}")
             cmd = [rocprof, "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--", *child]
             done = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
-                                  timeout=600)
+                                  timeout=240)
             files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
             if done.returncode != 0 or not files:
                 return None, f"rocprofv3 pass {index} failed (rc {done.returncode}): {done.stderr[-300:]}"
@@ -511,7 +511,7 @@ def main(argv=None):
             launches = max(timing["render_launches"], 1)
             kernel = ctx.render_kernel_name()
             profile, why_not, pmc_failure = None, None, None
-            if args.pmc and n_gpus == 1:
+            if not args.no_pmc and n_gpus == 1 and not args.sharded_env:
                 profile, pmc_failure = measure_pmc(args, kernel)
             if profile is None:
                 profile, why_not = committed_profile(kernel, frame, spp)
@@ -533,7 +533,7 @@ def main(argv=None):
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_from_committed_profile": traffic is not None and not live,
-                "traffic_measured_by": ("rocprofv3 --pmc child runs of this invocation (bench.py --pmc)" if live else
+                "traffic_measured_by": ("rocprofv3 --pmc child runs of this invocation" if live else
                                         "committed profile" if traffic is not None else None),
                 "traffic_profile": ({k: profile[k] for k in ("file", "commit", "config")} if profile
                                     else {"unavailable": why_not}),

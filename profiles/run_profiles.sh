@@ -16,8 +16,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace of the bench command at its default length so that the average launch duration is
 # the one bench.py's HIP events report; the PMC passes replay every kernel and use a short run
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $ARGS"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps $TRACE_STEPS --no-cpu-baseline $ARGS > $OUT/trace.log 2>&1
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pmc $ARGS"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps $TRACE_STEPS --no-cpu-baseline --no-pmc $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 grep "^{" $OUT/trace.log > $OUT/bench.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY \
