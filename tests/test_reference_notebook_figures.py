@@ -12,7 +12,6 @@ caption's move-count digit (the notebook's revision counted from 1).
 tests/test_gpu_notebook_figures.py does the same with the HIP path's frames."""
 
 import numpy as np
-import pytest
 
 from tests import notebook_figures as nf
 
