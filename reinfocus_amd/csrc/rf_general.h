@@ -165,35 +165,51 @@ RF_HD bool world_hit(const float *params, const int32_t *types, int n_shapes, in
     return true;
 }
 
+// physics.py:67-92 scatter, without the random_in_unit_sphere draw: the new ray and the
+// attenuation of a hit; q is the accepted sphere sample
+RF_HD void scatter_step(const HitRec &rec, float q0, float q1, float q2, float o[3], float d[3], float &ar, float &ag,
+                        float &ab)
+{
+    o[0] = rec.p[0];
+    o[1] = rec.p[1];
+    o[2] = rec.p[2];
+    d[0] = add2(rec.n[0], q0);
+    d[1] = add2(rec.n[1], q1);
+    d[2] = add2(rec.n[2], q2);
+    const bool red = checker_sign_general(rec.fu, rec.u) * checker_sign_general(rec.fv, rec.v) > 0;
+    ar = ar * (red ? 1.0f : 0.0f);
+    ag = ag * (red ? 0.0f : 1.0f);
+    ab = ab * 0.0f;
+}
+
+// physics.py:137-145: the sky seen along d times the attenuation gathered so far, in the float32
+// form proven equal to the float64 chain (rf_math.h)
+RF_HD Colour sky_colour(const float d[3], float ar, float ag, float ab)
+{
+    const float ud1 = unit_dir_y(d[0], d[1], d[2]);
+    const float white = sky_white(ud1);
+    Colour c;
+    c.r = add2(white, sky_blue(ud1, kSkyHalf[0])) * ar;
+    c.g = add2(white, sky_blue(ud1, kSkyHalf[1])) * ag;
+    c.b = add2(white, sky_blue(ud1, kSkyHalf[2])) * ab;
+    return c;
+}
+
+constexpr int kMaxBounces = 50; // physics.py:118
+
 RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes, int width, const float o_in[3],
                          const float d_in[3], Rng &g)
 {
     float o[3] = {o_in[0], o_in[1], o_in[2]}, d[3] = {d_in[0], d_in[1], d_in[2]};
     float ar = 1.0f, ag = 1.0f, ab = 1.0f;
-    for (int bounce = 0; bounce < 50; ++bounce) {
+    for (int bounce = 0; bounce < kMaxBounces; ++bounce) {
         HitRec rec;
         if (world_hit(params, types, n_shapes, width, o, d, 0.001f, 1000000.0f, rec)) {
             float q0, q1, q2;
             sphere_sample(g, q0, q1, q2);
-            o[0] = rec.p[0];
-            o[1] = rec.p[1];
-            o[2] = rec.p[2];
-            d[0] = add2(rec.n[0], q0);
-            d[1] = add2(rec.n[1], q1);
-            d[2] = add2(rec.n[2], q2);
-            const bool red = checker_sign_general(rec.fu, rec.u) * checker_sign_general(rec.fv, rec.v) > 0;
-            ar = ar * (red ? 1.0f : 0.0f);
-            ag = ag * (red ? 0.0f : 1.0f);
-            ab = ab * 0.0f;
+            scatter_step(rec, q0, q1, q2, o, d, ar, ag, ab);
         } else {
-            // physics.py:137-145 in the float32 form proven equal to the float64 chain (rf_math.h)
-            const float ud1 = unit_dir_y(d[0], d[1], d[2]);
-            const float white = sky_white(ud1);
-            Colour c;
-            c.r = add2(white, sky_blue(ud1, kSkyHalf[0])) * ar;
-            c.g = add2(white, sky_blue(ud1, kSkyHalf[1])) * ag;
-            c.b = add2(white, sky_blue(ud1, kSkyHalf[2])) * ab;
-            return c;
+            return sky_colour(d, ar, ag, ab);
         }
     }
     return Colour{0.0f, 0.0f, 0.0f};
@@ -217,6 +233,49 @@ RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
     return c;
 }
 
+// RN32(RN64(x + xi) / w) by the 3-operation quotient of rf_math.h for the frame sizes it is
+// proven for (every w <= 4096, see pixel_coord_div), by the IEEE division otherwise
+struct GeneralFrame {
+    int h, w;
+    bool quick;
+    double w64, h64, rw64, rh64;
+};
+
+RF_HD GeneralFrame general_frame(int h, int w)
+{
+    GeneralFrame f;
+    f.h = h;
+    f.w = w;
+    f.quick = w <= 4096 && h <= 4096;
+    f.w64 = (double)w;
+    f.h64 = (double)h;
+    f.rw64 = 1.0 / f.w64;
+    f.rh64 = 1.0 / f.h64;
+    return f;
+}
+
+// render.py:61-66: the jittered coordinates of one sample, two draws (x first)
+RF_HD void general_coords(Rng &g, int x, int y, const GeneralFrame &f, float &s, float &t)
+{
+    const float xi = rng_uniform(g);
+    s = f.quick ? pixel_coord_div(x, xi, f.w64, f.rw64) : pixel_coord_literal(x, xi, f.w);
+    const float yi = rng_uniform(g);
+    t = f.quick ? pixel_coord_div(y, yi, f.h64, f.rh64) : pixel_coord_literal(y, yi, f.h);
+}
+
+// camera.get_ray (camera.py:307-350) for a general camera frame; p is the lens-disc sample
+RF_HD void general_ray(const CamDyn &dyn, const CamStatic &cs, float p0, float p1, float s, float t, float o[3],
+                       float d[3])
+{
+    const double rd0 = (double)p0 * cs.lens_radius, rd1 = (double)p1 * cs.lens_radius;
+    o[0] = add3(cs.ox, (float)((double)cs.ux * rd0), (float)((double)cs.vx * rd1));
+    o[1] = add3(cs.oy, (float)((double)cs.uy * rd0), (float)((double)cs.vy * rd1));
+    o[2] = add3(cs.oz, (float)((double)cs.uz * rd0), (float)((double)cs.vz * rd1));
+    d[0] = add3(dyn.llx, dyn.hx * s, dyn.vx * t) - o[0];
+    d[1] = add3(dyn.lly, dyn.hy * s, dyn.vy * t) - o[1];
+    d[2] = add3(dyn.llz, dyn.hz * s, dyn.vz * t) - o[2];
+}
+
 // one pixel of device_render
 RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, const GeneralCamera &cam,
                                 const float *params, const int32_t *types, int n_shapes, int width, float &cr,
@@ -226,23 +285,14 @@ RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, con
     const CamStatic cs{cam.f[9],  cam.f[10], cam.f[11], cam.f[12], cam.f[13],
                        cam.f[14], cam.f[15], cam.f[16], cam.f[17], cam.lens_radius, 0.0f, 0.0f, 0};
     cr = cg = cb = 0.0f;
-    // RN32(RN64(x + xi) / w) by the 3-operation quotient of rf_math.h for the frame sizes it is
-    // proven for (every w <= 4096, see pixel_coord_div), by the IEEE division otherwise
-    const bool quick = w <= 4096 && h <= 4096;
-    const double w64 = (double)w, h64 = (double)h, rw64 = 1.0 / w64, rh64 = 1.0 / h64;
+    const GeneralFrame frame = general_frame(h, w);
     for (int k = 0; k < spp; ++k) {
-        const float xi = rng_uniform(g);
-        const float s = quick ? pixel_coord_div(x, xi, w64, rw64) : pixel_coord_literal(x, xi, w);
-        const float yi = rng_uniform(g);
-        const float t = quick ? pixel_coord_div(y, yi, h64, rh64) : pixel_coord_literal(y, yi, h);
+        float s, t;
+        general_coords(g, x, y, frame, s, t);
         float p0, p1;
         disc_sample(g, p0, p1);
-        const double rd0 = (double)p0 * cs.lens_radius, rd1 = (double)p1 * cs.lens_radius;
-        const float o[3] = {add3(cs.ox, (float)((double)cs.ux * rd0), (float)((double)cs.vx * rd1)),
-                            add3(cs.oy, (float)((double)cs.uy * rd0), (float)((double)cs.vy * rd1)),
-                            add3(cs.oz, (float)((double)cs.uz * rd0), (float)((double)cs.vz * rd1))};
-        const float d[3] = {add3(dyn.llx, dyn.hx * s, dyn.vx * t) - o[0], add3(dyn.lly, dyn.hy * s, dyn.vy * t) - o[1],
-                            add3(dyn.llz, dyn.hz * s, dyn.vz * t) - o[2]};
+        float o[3], d[3];
+        general_ray(dyn, cs, p0, p1, s, t, o, d);
         const Colour c = find_colour(params, types, n_shapes, width, o, d, g);
         cr = add2(cr, c.r);
         cg = add2(cg, c.g);
