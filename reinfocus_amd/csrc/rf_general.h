@@ -124,7 +124,7 @@ RF_HD void rectangle_texture(const float *rp, HitRec &r)
 }
 
 // sign of sin((f * pi) * u) as the reference evaluates it in float64: -1, 0, +1 (NaN -> 0)
-RF_COLD int checker_sign_general(float f, float u)
+RF_COLD int checker_sign_f64(float f, float u)
 {
     const double m = (double)f * (double)u; // exact: two f32 factors
     if (!(m == m) || m - m != 0.0)          // NaN or infinite argument: sin is NaN
@@ -138,6 +138,23 @@ RF_COLD int checker_sign_general(float f, float u)
     }
     const double s = sin(((double)f * kPi) * (double)u);
     return s > 0.0 ? 1 : (s < 0.0 ? -1 : 0);
+}
+
+// The same sign from float32 arithmetic whenever that is safe: m32 = RN32(f * u) is within
+// 2^-24 |m| of the exact product m, so if m32 lies further than 4 * 2^-22 * max(|m32|, 1) from both
+// neighbouring integers, floor(m) == floor(m32) and m is nowhere near the band in which
+// checker_sign_f64 consults sin -- the sign is (-1)^floor(m32).  Everything else (about one
+// coordinate in a million, NaN, huge arguments) takes the float64 function.
+RF_HD int checker_sign_general(float f, float u)
+{
+    const float m = f * u;
+    const float fl = __builtin_floorf(m);
+    const float fr = m - fl; // exact for |m| < 2^23
+    const float am = __builtin_fabsf(m);
+    const float margin = (am > 1.0f ? am : 1.0f) * 9.5367431640625e-07f; // 2^-20
+    if (am < 65536.0f && fr > margin && fr < 1.0f - margin) // false for NaN
+        return ((int)fl & 1) ? -1 : 1;
+    return checker_sign_f64(f, u);
 }
 
 RF_HD bool world_hit(const float *params, const int32_t *types, int n_shapes, int width, const float o[3],
