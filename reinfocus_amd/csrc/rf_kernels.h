@@ -359,7 +359,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
 // lanes along x, frame bytes staged through LDS.  Held to 5 waves per SIMD: with the float64
 // library calls inlined the kernel needed 208 VGPRs (2 waves per SIMD, 42.5 G samples/s on
 // one-rectangle scenes); with them out of line 112 (4 waves: 55.6), and at 96 registers with six
-// spilled (5 waves) 58.0 -- tools/bench_general.py, profiles/README.md.
+// spilled (5 waves) 58.0 -- tools/bench_general.py, profiles/README.md.  (Sphere scenes gained another
+// 13 % from deciding a hit's checker colour in float32 where that is safe: rf_general.h sphere_red.)
 // ---------------------------------------------------------------------------
 struct GeneralArgs {
     uint8_t *frames;

@@ -72,6 +72,12 @@ __global__ void probe_checker_kernel(const float *f, const float *u, int *sign, 
         sign[i] = rf::checker_sign_general(f[i], u[i]);
 }
 
+__global__ void probe_sphere_red_kernel(const float *normals, const float *fu, const float *fv, int *red, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        red[i] = probe::sphere_red_fast(normals + 3 * i, fu[i], fv[i]);
+}
+
 namespace {
 template <typename F>
 int with_buffers(const void *const *host_in, const size_t *in_bytes, int n_in, void *host_out, size_t out_bytes, F launch)
@@ -125,5 +131,15 @@ extern "C" int gc_probe_checker(const float *f, const float *u, int *sign, uint6
     return with_buffers(in, bytes, 2, sign, n * 4, [&](void **d, void *o) {
         hipLaunchKernelGGL(probe_checker_kernel, dim3(1024), dim3(256), 0, 0, (const float *)d[0], (const float *)d[1],
                            (int *)o, n);
+    });
+}
+
+extern "C" int gc_probe_sphere_red(const float *normals, const float *fu, const float *fv, int *red, uint64_t n)
+{
+    const void *in[3] = {normals, fu, fv};
+    const size_t bytes[3] = {n * 12, n * 4, n * 4};
+    return with_buffers(in, bytes, 3, red, n * 4, [&](void **d, void *o) {
+        hipLaunchKernelGGL(probe_sphere_red_kernel, dim3(1024), dim3(256), 0, 0, (const float *)d[0], (const float *)d[1],
+                           (const float *)d[2], (int *)o, n);
     });
 }

@@ -29,4 +29,10 @@ RF_HD void sphere_uv(const float n[3], float uv[2])
     uv[1] = (float)(acos(-(double)n[1]) / rf::kPi);
 }
 
+// the checker colour of a sphere hit: the float32 fast path with its fallback, and the reference's
+// float64 expressions alone
+RF_HD int sphere_red_fast(const float n[3], float fu, float fv) { return rf::sphere_red(n, fu, fv) ? 1 : 0; }
+RF_HD void sphere_uv_fast(const float n[3], float uv[2]) { rf::sphere_uv_approx(n, uv[0], uv[1]); }
+RF_HD int sphere_red_exact(const float n[3], float fu, float fv) { return rf::sphere_red_exact(n, fu, fv) ? 1 : 0; }
+
 } // namespace probe

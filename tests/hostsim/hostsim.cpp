@@ -301,6 +301,23 @@ int hs_probe_checker_literal(const float *f, const float *u, int *sign, uint64_t
     return 0;
 }
 
+// checker colour of sphere hits: mode 0 = fast path + fallback, 1 = float64 expressions alone
+int hs_probe_sphere_red(int mode, const float *normals, const float *fu, const float *fv, int *red, uint64_t n)
+{
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        red[i] = mode ? probe::sphere_red_exact(normals + 3 * i, fu[i], fv[i])
+                      : probe::sphere_red_fast(normals + 3 * i, fu[i], fv[i]);
+    return 0;
+}
+
+int hs_probe_uv_approx(const float *normals, float *uv, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        probe::sphere_uv_fast(normals + 3 * i, uv + 2 * i);
+    return 0;
+}
+
 int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)
 {
     for (uint64_t i = 0; i < n; ++i)

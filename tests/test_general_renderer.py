@@ -231,3 +231,56 @@ def test_checker_shortcut_equals_the_literal_sine_sign():
     hs.hs_probe_checker(ptr(f), ptr(u), ptr(own), ctypes.c_uint64(n))
     assert np.array_equal(literal, own)
     assert (literal == 0).sum() > 0 and (literal == 1).sum() > n // 4 and (literal == -1).sum() > n // 4
+
+
+def _normals_on_and_near_checker_edges(rng, n):
+    """Unit normals whose sphere texture coordinates sit on / next to checker edges for the
+    frequencies that come with them (70 %), or anywhere (30 %)."""
+    fu = rng.integers(1, 41, n).astype(np.float32)
+    fv = rng.integers(1, 41, n).astype(np.float32)
+    offsets = [0, 0, 1e-9, -1e-9, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4]
+    anywhere = rng.random(n) < 0.3
+    u = np.where(anywhere, rng.uniform(0, 2, n),
+                 np.clip(rng.integers(0, 81, n) / fu.astype(np.float64) + rng.choice(offsets, n), 0, 2))
+    v = np.where(anywhere, rng.uniform(0, 1, n),
+                 np.clip(rng.integers(0, 41, n) / fv.astype(np.float64) + rng.choice(offsets, n), 0, 1))
+    theta, phi = u * np.pi - np.pi, v * np.pi  # atan2(-z, x) = theta, acos(-y) = phi
+    ring = np.sin(phi)
+    normals = np.stack([ring * np.cos(theta), -np.cos(phi), -ring * np.sin(theta)], axis=1).astype(np.float32)
+    return np.ascontiguousarray(normals), fu, fv
+
+
+def test_sphere_checker_fast_path_equals_the_float64_expressions():
+    """rf_general.h sphere_red: float32 approximations of sphere.uv decide the checker colour of a
+    sphere hit wherever the products frequency * coordinate are safely away from every integer; the
+    reference's float64 atan2 / acos / sin decide otherwise.  (i) the approximations are within
+    5e-7 of the float64 values (the margin assumes 1e-6); (ii) fast path + fallback and the float64
+    expressions alone give the same colour for normals on and next to every checker edge."""
+    import subprocess
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostsim")])
+    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    v = rng.normal(size=(n, 3))
+    normals = np.ascontiguousarray((v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32))
+    normals[: n // 50, 2] = 0.0
+    normals[n // 50: n // 25, 0] = 0.0
+    normals[n // 25: n // 20, 1] = np.float32(1 - 1e-7) * rng.choice([-1, 1], n // 20 - n // 25)
+    approx = np.zeros((n, 2), dtype=np.float32)
+    exact = np.zeros((n, 2), dtype=np.float32)
+    hs.hs_probe_uv_approx(ptr(normals), ptr(approx), ctypes.c_uint64(n))
+    hs.hs_probe_uv(ptr(normals), ptr(exact), ctypes.c_uint64(n))
+    error = np.abs(approx.astype(np.float64) - exact)
+    error[:, 0] = np.minimum(error[:, 0], np.abs(error[:, 0] - 2))  # u = 0 and u = 2 are the same direction
+    assert np.isfinite(exact).all() and error.max() < 5e-7
+
+    n = 4_000_000
+    normals, fu, fv = _normals_on_and_near_checker_edges(rng, n)
+    fast = np.zeros(n, dtype=np.int32)
+    reference = np.zeros(n, dtype=np.int32)
+    hs.hs_probe_sphere_red(0, ptr(normals), ptr(fu), ptr(fv), ptr(fast), ctypes.c_uint64(n))
+    hs.hs_probe_sphere_red(1, ptr(normals), ptr(fu), ptr(fv), ptr(reference), ctypes.c_uint64(n))
+    assert np.array_equal(fast, reference)
+    assert 0.4 < reference.mean() < 0.6

@@ -128,3 +128,28 @@ def test_device_math_library_reaches_the_same_float32():
     hs.hs_probe_checker_literal(ptr(f), ptr(u), ptr(literal), count)
     assert gc.gc_probe_checker(ptr(f), ptr(u), ptr(device), count) == 0
     assert np.array_equal(literal, device)
+
+
+def test_sphere_checker_fast_path_on_the_device():
+    """The float32 fast path of a sphere hit's checker colour (rf_general.h sphere_red) as the GPU
+    executes it -- v_rcp_f32 / v_sqrt_f32 approximations, fallback through the device math library
+    -- against the reference's float64 expressions evaluated on the host with glibc, for normals
+    on and next to every checker edge."""
+    import ctypes
+    import subprocess
+
+    from tests.test_general_renderer import _normals_on_and_near_checker_edges
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "gpucheck"), "libgpucheck.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "hostsim")])
+    gc = ctypes.CDLL(os.path.join(here, "gpucheck", "libgpucheck.so"))
+    hs = ctypes.CDLL(os.path.join(here, "hostsim", "libhostsim.so"))
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    n = 4_000_000
+    normals, fu, fv = _normals_on_and_near_checker_edges(np.random.default_rng(9), n)
+    device = np.zeros(n, dtype=np.int32)
+    reference = np.zeros(n, dtype=np.int32)
+    assert gc.gc_probe_sphere_red(ptr(normals), ptr(fu), ptr(fv), ptr(device), ctypes.c_uint64(n)) == 0
+    hs.hs_probe_sphere_red(1, ptr(normals), ptr(fu), ptr(fv), ptr(reference), ctypes.c_uint64(n))
+    assert np.array_equal(device, reference)
