@@ -59,6 +59,7 @@ def lib():
         L.orc_random_in_unit_sphere.argtypes = [p, p]
         L.orc_get_ray.argtypes = [p, p, ctypes.c_float, ctypes.c_float, p, p, p]
         L.orc_uv.argtypes = [p] + [ctypes.c_float] * 4 + [p]
+        L.orc_vector_op.argtypes = [ctypes.c_int, p, p, p, ctypes.c_float, p]
         L.orc_fast_hit.argtypes = [p, p, p, ctypes.c_float, ctypes.c_float, p]
         L.orc_fast_hit.restype = ctypes.c_int
         L.orc_colour_checkerboard.argtypes = [p, p, p]
@@ -139,6 +140,18 @@ def get_ray(dyn, cs, s, t, state):
     d = np.zeros(3, dtype=np.float32)
     lib().orc_get_ray(_ptr(dyn), ctypes.byref(cs), float(s), float(t), _ptr(state), _ptr(o), _ptr(d))
     return o, d
+
+
+VECTOR_OPS = {"add": 0, "sub": 1, "smul": 2, "dot": 3, "squared_length": 4, "length": 5, "norm": 6,
+              "point_at_parameter": 7, "dot2": 8}
+
+
+def vector_op(name, a, b=(0, 0, 0), c=(0, 0, 0), s=0.0):
+    """graphics/vector.py device helpers as the oracle's renderers use them; float32[3]."""
+    a, b, c = (_f32(np.resize(np.asarray(v, dtype=np.float32), 3)) for v in (a, b, c))
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_vector_op(VECTOR_OPS[name], _ptr(a), _ptr(b), _ptr(c), float(s), _ptr(out))
+    return out
 
 
 def uv(point, x_min, x_max, y_min, y_max):

@@ -301,6 +301,53 @@ void orc_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_
     }
 }
 
+/* graphics/vector.py device helpers, exported one by one so that the reference's own known
+ * answers for them (tests/graphics/vector_test.py, ray_test.py) can be asserted against the very
+ * helpers the renderers above are written with.
+ * op: 0 d_add_v3f((a, b, c))  1 d_sub_v3f(a, b)  2 d_smul_v3f(a, s)  3 d_dot_v3f(a, b) -> out[0]
+ *     4 d_squared_length_v3f(a) -> out[0]  5 d_length_v3f(a) -> out[0]  6 d_norm_v3f(a)
+ *     7 ray.point_at_parameter(origin a, direction b, s)  8 d_dot_v2f(a, b) -> out[0] */
+void orc_vector_op(int op, const float a[3], const float b[3], const float c[3], float s, float out[3])
+{
+    out[0] = out[1] = out[2] = 0.0f;
+    switch (op) {
+    case 0:
+        for (int k = 0; k < 3; ++k)
+            out[k] = add3(a[k], b[k], c[k]);
+        break;
+    case 1:
+        for (int k = 0; k < 3; ++k)
+            out[k] = a[k] - b[k];
+        break;
+    case 2:
+        for (int k = 0; k < 3; ++k)
+            out[k] = a[k] * s;
+        break;
+    case 3:
+        out[0] = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+        break;
+    case 4:
+        out[0] = squared_length(a);
+        break;
+    case 5:
+        out[0] = (float)sqrt((double)squared_length(a));
+        break;
+    case 6: {
+        const float inv = 1.0f / (float)sqrt((double)squared_length(a));
+        for (int k = 0; k < 3; ++k)
+            out[k] = a[k] * inv;
+        break;
+    }
+    case 7: /* ray.py:29-40: origin + d_smul_v3f(direction, t), summed by d_add_v3f */
+        for (int k = 0; k < 3; ++k)
+            out[k] = add2(a[k], b[k] * s);
+        break;
+    default:
+        out[0] = a[0] * b[0] + a[1] * b[1];
+        break;
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* general renderer: render.py:31-119, world.py:126-167, physics.py:95-145,  */
 /* sphere.py:40-117, rectangle.py:49-99                                      */

@@ -92,6 +92,9 @@ double orc_focus_value(const uint8_t *rgb, int h, int w, int gray_mode);
 void orc_focus_values(const uint8_t *frames, int n, int h, int w, int gray_mode,
                       double *out, int n_threads);
 
+/* graphics/vector.py device helpers (see rf_oracle.c for the op codes). */
+void orc_vector_op(int op, const float a[3], const float b[3], const float c[3], float s, float out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,3 +295,20 @@ def test_cutil_known_answers():
     for bad in ((16, 16), (1, 0, 16), (1, -2, 16)):
         with pytest.raises(AssertionError):
             cutil.check_block_shape(bad)
+
+
+def test_vector_and_ray_helpers(oracle):
+    """tests/graphics/vector_test.py:48-376 and ray_test.py:40-60 of the reference: the device
+    helpers' known answers, on the helpers the oracle's renderers are written with."""
+    v = oracle.vector_op
+    testing.assert_allclose(v("sub", (3, 4, 0), (2, 1, 0))[:2], (1, 3))              # d_sub_v2f
+    testing.assert_allclose(v("smul", (1, 2, 0), s=3)[:2], (3, 6))                    # d_smul_v2f
+    assert v("dot2", (2, 3, 0), (4, 5, 0))[0] == 23                                   # d_dot_v2f
+    testing.assert_allclose(v("add", (1, 2, 3), (4, 5, 6), (7, 8, 9)), (12, 15, 18))  # d_add_v3f
+    testing.assert_allclose(v("sub", (4, 5, 6), (3, 2, 1)), (1, 3, 5))                # d_sub_v3f
+    testing.assert_allclose(v("smul", (1, 2, 3), s=3), (3, 6, 9))                     # d_smul_v3f
+    assert v("dot", (1, 2, 3), (4, 5, 6))[0] == 32                                    # d_dot_v3f
+    assert v("squared_length", (1, 2, 3))[0] == 14                                    # d_squared_length_v3f
+    assert v("length", (2, 3, 6))[0] == 7                                             # d_length_v3f
+    testing.assert_allclose(v("norm", (1, -1, 2)), np.array([1, -1, 2]) / np.sqrt(6), rtol=1e-6)  # d_norm_v3f
+    testing.assert_allclose(v("point_at_parameter", (1, 2, 3), (4, 5, 6), s=2), (9, 12, 15))      # ray.py:29-40
