@@ -43,6 +43,13 @@ constexpr int kSets = RF_SETS;
 #ifndef RF_TWO_ROUNDS_MIN
 #define RF_TWO_ROUNDS_MIN 64 // entries above which the packing round is used (128: 140.0 instead of 142.9)
 #endif
+#ifndef RF_TWO_ROUNDS_MIN_DISC
+// The disc tails never take the packing round: their ~165 stragglers per call finish on the three
+// waves they fill (a rejected disc attempt is accepted next time with probability 0.785, so the
+// per-wave tails are short) with two barriers instead of three.  64 / 128 / 256 (= never):
+// 122.3 / 122.2 / 124.0 k env-steps/s.
+#define RF_TWO_ROUNDS_MIN_DISC 256
+#endif
 #ifndef RF_R1_SPHERE
 #define RF_R1_SPHERE 2 // attempts per entry in the packing round (1 / 3: 142.9 / 144.0 with one in-wave attempt)
 #endif
@@ -134,7 +141,7 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
     if (total == 0) // block-uniform
         return 0;
 #if RF_TWO_ROUNDS
-    if (total > RF_TWO_ROUNDS_MIN) { // block-uniform
+    if (total > (DIM == 2 ? RF_TWO_ROUNDS_MIN_DISC : RF_TWO_ROUNDS_MIN)) { // block-uniform
         // Round 1: the packed entries make a bounded number of attempts on as many waves as they
         // fill; the survivors are packed again -- into the other parity's state buffer, idle
         // during this call -- and finished in round 2 by (usually) a single wave, instead of every
