@@ -50,6 +50,9 @@ constexpr int kSets = RF_SETS;
 // 122.3 / 122.2 / 124.0 k env-steps/s.
 #define RF_TWO_ROUNDS_MIN_DISC 256
 #endif
+#ifndef RF_COOP2_DISC_TRIPS
+#define RF_COOP2_DISC_TRIPS 1 // in-wave disc attempts before the cooperative call (2: see DESIGN.md)
+#endif
 #ifndef RF_R1_SPHERE
 #define RF_R1_SPHERE 2 // attempts per entry in the packing round (1 / 3: 142.9 / 144.0 with one in-wave attempt)
 #endif
@@ -349,8 +352,13 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             for (int i = 0; i < 4; ++i)
                 w[j][i] = RF_WORD_INIT;
             need[j] = gk.live_of(j);
-            if (need[j] && disc_attempt(g[j], w[j]))
-                need[j] = false;
+#pragma unroll
+            for (int trip = 0; trip < RF_COOP2_DISC_TRIPS; ++trip) {
+                if (trip == 0 || __any(need[j])) { // wave-uniform
+                    if (need[j] && disc_attempt(g[j], w[j]))
+                        need[j] = false;
+                }
+            }
         }
         coop_finish2<2>(lds, 0, need, g, w);
 
