@@ -80,49 +80,99 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(world, argv):
+def launch_ranks(world, argv, total_timeout=None):
     """Starts `world` children of this script, one rank per GPU, relays rank 0's stdout (the JSON
     line) and returns the worst exit code.  A rank that fails takes the others down with it (they
-    would wait for it at the next barrier): they are ended by PID, never by pattern."""
-    port = free_port()
-    children = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if rank == 0 else sys.stderr
-        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                         stdout=out, cwd=os.getcwd()))
+    would wait for it at the next barrier).  Children are only ever ended by PID: terminate(), then
+    kill() after a grace period; the same happens when this launcher is interrupted or terminated
+    (it never touches the GPU, so handling the signal here is safe) and when `total_timeout`
+    seconds (REINFOCUS_BENCH_LAUNCH_TIMEOUT, default 3000) pass."""
+    import signal
     import threading
 
-    def relay(pipe):  # rank 0's JSON line goes to stdout, anything else it printed to stderr
-        for line in iter(pipe.readline, b""):
-            text = line.decode("utf-8", "replace")
-            out = sys.stdout if text.lstrip().startswith("{") else sys.stderr
-            out.write(text)
-            out.flush()
+    if total_timeout is None:
+        total_timeout = float(os.environ.get("REINFOCUS_BENCH_LAUNCH_TIMEOUT", "3000"))
+    port = free_port()
+    children = []
 
-    pump = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
-    pump.start()
+    def end_children(grace=5.0):
+        alive = [c for c in children if c.poll() is None]
+        for child in alive:
+            child.terminate()
+        deadline = time.monotonic() + grace
+        for child in alive:
+            try:
+                child.wait(timeout=max(0.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                child.kill()
+        for child in alive:
+            try:
+                child.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    class Interrupted(Exception):
+        pass
+
+    def on_signal(signum, frame):
+        raise Interrupted(signum)
+
+    previous = {}
+    for signum in (signal.SIGTERM, signal.SIGINT):
+        try:
+            previous[signum] = signal.signal(signum, on_signal)
+        except ValueError:  # not the main thread (tests): the finally clause still cleans up
+            pass
     worst = 0
-    pending = set(range(world))
-    failed_at = None
-    while pending:
-        for rank in sorted(pending):
-            rc = children[rank].poll()
-            if rc is None:
-                continue
-            pending.discard(rank)
-            if rc != 0:
-                print(f"bench.py: rank {rank} exited with code {rc}", file=sys.stderr)
-                worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
-                failed_at = failed_at or time.monotonic()
-        if failed_at is not None and pending and time.monotonic() - failed_at > 10.0:
-            for rank in pending:  # the survivors are stuck at a barrier
-                children[rank].terminate()
-            failed_at = time.monotonic() + 3600.0
-        time.sleep(0.05)
-    pump.join(timeout=5.0)
+    try:
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            out = subprocess.PIPE if rank == 0 else sys.stderr
+            children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                             stdout=out, cwd=os.getcwd()))
+
+        def relay(pipe):  # rank 0's JSON line goes to stdout, anything else it printed to stderr
+            for line in iter(pipe.readline, b""):
+                text = line.decode("utf-8", "replace")
+                out = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+                out.write(text)
+                out.flush()
+
+        pump = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
+        pump.start()
+        started = time.monotonic()
+        pending = set(range(world))
+        failed_at = None
+        while pending:
+            for rank in sorted(pending):
+                rc = children[rank].poll()
+                if rc is None:
+                    continue
+                pending.discard(rank)
+                if rc != 0:
+                    print(f"bench.py: rank {rank} exited with code {rc}", file=sys.stderr)
+                    worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+                    failed_at = failed_at or time.monotonic()
+            if pending and failed_at is not None and time.monotonic() - failed_at > 10.0:
+                print(f"bench.py: ending ranks {sorted(pending)} (stuck behind a failed rank)", file=sys.stderr)
+                end_children()  # the survivors are stuck at a barrier
+                pending.clear()
+            elif pending and time.monotonic() - started > total_timeout:
+                print(f"bench.py: ranks {sorted(pending)} still running after {total_timeout:.0f} s", file=sys.stderr)
+                worst = worst or 124
+                end_children()
+                pending.clear()
+            time.sleep(0.05)
+        pump.join(timeout=5.0)
+    except Interrupted as stop:
+        print(f"bench.py: launcher got signal {stop.args[0]}, ending the ranks", file=sys.stderr)
+        worst = 128 + int(stop.args[0])
+    finally:
+        end_children()
+        for signum, handler in previous.items():
+            signal.signal(signum, handler)
     return worst if 0 <= worst < 256 else 1
 
 
@@ -409,6 +459,13 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.sharded_env:
         raise SystemExit(launch_ranks(args.gpus, raw))
 
+    if args.plumbing_test and os.environ.get("REINFOCUS_BENCH_HANG_RANK") == os.environ.get("RANK", "0"):
+        import signal  # test hook: a rank that hangs and ignores SIGTERM must still be ended (by PID)
+
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(3600)
+    if args.plumbing_test and os.environ.get("REINFOCUS_BENCH_FAIL_EARLY_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)  # test hook: a rank that dies before the rendezvous
     ranks = Ranks(args.gpus, single_process=args.sharded_env)
     if args.plumbing_test and os.environ.get("REINFOCUS_BENCH_FAIL_RANK") == str(ranks.rank):
         sys.exit(3)  # test hook: a rank that dies must fail the whole launch

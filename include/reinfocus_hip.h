@@ -214,6 +214,23 @@ int rf_env_render(rf_ctx *ctx, int frame_height, int spp, uint8_t *host_out);
  * prints: episode_ender.py:191-207, :646-656). */
 int rf_env_get_counters(rf_ctx *ctx, int32_t *host_steps, int32_t *host_diverging);
 
+/* How the last rf_env_step ran -- the three are different schedules of the same kernels with the same
+ * results (tests/test_gpu_environment.py runs each against the reference's numpy glue):
+ *   RF_ENV_BRANCH_ONE_SYNC    whole step enqueued at once, auto-reset launch sized for all n slots,
+ *                             one host synchronisation (small configurations);
+ *   RF_ENV_BRANCH_GRAPH       the same, replayed as one hipGraph (from such a configuration's second
+ *                             step on; REINFOCUS_ENV_GRAPH=0 disables);
+ *   RF_ENV_BRANCH_COUNT_SIZED rf_env_step_begin + rf_env_step_end: one host round trip mid-step, the
+ *                             auto-reset launch sized by the count (configurations whose full render
+ *                             has more than REINFOCUS_ENV_ONE_SYNC_MAX = 65536 blocks, e.g. the
+ *                             benchmarked 4096 x 256 x 256).
+ * No reference counterpart (vector_environment.py:104-164 is one synchronous schedule); diagnostic. */
+#define RF_ENV_BRANCH_NONE 0
+#define RF_ENV_BRANCH_ONE_SYNC 1
+#define RF_ENV_BRANCH_GRAPH 2
+#define RF_ENV_BRANCH_COUNT_SIZED 3
+int rf_env_last_step_branch(rf_ctx *ctx, int *branch);
+
 /* Current states float32[n][2] (tests / checkpoint). */
 int rf_env_get_states(rf_ctx *ctx, float *host_states);
 

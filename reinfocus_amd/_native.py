@@ -54,6 +54,7 @@ SYMBOLS = (
     "rf_env_scene_len",
     "rf_env_render",
     "rf_env_get_counters",
+    "rf_env_last_step_branch",
     "rf_render_kernel_name",
 )
 
@@ -137,6 +138,7 @@ def load():
     lib.rf_env_scene_len.argtypes = [vp, ctypes.POINTER(i32)]
     lib.rf_env_render.argtypes = [vp, i32, i32, vp]
     lib.rf_env_get_counters.argtypes = [vp, vp, vp]
+    lib.rf_env_last_step_branch.argtypes = [vp, ctypes.POINTER(i32)]
     lib.rf_render_kernel_name.restype = ctypes.c_char_p
     lib.rf_render_kernel_name.argtypes = [vp]
     _lib = lib
@@ -324,6 +326,12 @@ class Context:
         diverging = np.empty(self._env_n, dtype=np.int32)
         _check(self._lib.rf_env_get_counters(self._h, _ptr(steps), _ptr(diverging)))
         return steps, diverging
+
+    def env_last_step_branch(self):
+        """'none' | 'one-sync' | 'graph' | 'count-sized': how the last rf_env_step was scheduled."""
+        branch = ctypes.c_int(0)
+        _check(self._lib.rf_env_last_step_branch(self._h, ctypes.byref(branch)))
+        return ("none", "one-sync", "graph", "count-sized")[branch.value]
 
     def render_kernel_name(self):
         return self._lib.rf_render_kernel_name(self._h).decode()

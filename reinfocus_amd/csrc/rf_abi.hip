@@ -110,6 +110,9 @@ struct rf_ctx {
     int env_scene_len = 0; // environments of the scene set uploaded last: n after a full render, k after a partial one
     int env_pending = -1; // >= 0: rf_env_step_begin ran and that many environments wait for rf_env_step_end
     bool env_graph_fail_once = false; // REINFOCUS_ENV_GRAPH_FAIL=1 (tests): the first instantiation "fails"
+    int env_last_branch = RF_ENV_BRANCH_NONE; // rf_env_last_step_branch
+    long env_one_sync_max = 65536; // blocks of a full render up to which rf_env_step runs without the mid-step round
+                                   // trip (REINFOCUS_ENV_ONE_SYNC_MAX; tests set 0 to reach the count-sized branch at small sizes)
     const char *render_kernel = "none"; // the render kernel the last launch used (rf_render_kernel_name)
     void *general_scratch = nullptr;    // scene arrays of rf_render_general (grown on demand)
     size_t general_scratch_bytes = 0;
@@ -318,6 +321,12 @@ int rf_create(int device, rf_ctx **out)
         ctx->focus_quad = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
         ctx->env_graph_fail_once = v[0] == '1';
+    if (const char *v = getenv("REINFOCUS_ENV_ONE_SYNC_MAX")) {
+        char *end = nullptr;
+        const long limit = strtol(v, &end, 10);
+        if (end != v && limit >= 0)
+            ctx->env_one_sync_max = limit;
+    }
 
     std::vector<rf::Mat128> tables;
     if (!rf::h_build_jump_tables(rf::kSeedMats, tables)) {
@@ -973,7 +982,7 @@ bool env_one_sync(const rf_ctx *ctx)
 {
     const int n = ctx->env_host.n, fh = ctx->env_host.frame_height;
     const long tiles = (long)((fh + rf::kTileW - 1) / rf::kTileW) * ((fh + rf::kTileH2 - 1) / rf::kTileH2);
-    return (long)n * tiles <= 65536;
+    return (long)n * tiles <= ctx->env_one_sync_max;
 }
 
 // Enqueues one whole step on the ctx's stream without waiting for anything: uploads, the full
@@ -1098,6 +1107,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                 return rc;
             RF_HIP(hipGetLastError());
             RF_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->env_last_branch = RF_ENV_BRANCH_ONE_SYNC;
         } else {
             if (ctx->h_stage_bytes < bytes) {
                 if (ctx->env_graph)
@@ -1141,6 +1151,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     ctx->env_steps += 1;
                     ctx->env_scene_len = k > 0 ? k : n;
                     ctx->env_last_partial = k > 0;
+                    ctx->env_last_branch = RF_ENV_BRANCH_ONE_SYNC;
                     if (host_n_reset)
                         *host_n_reset = k;
                     return RF_OK;
@@ -1154,6 +1165,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             memcpy(host_rewards, st + o_rew, (size_t)n * 8);
             memcpy(host_truncated, st + o_tru, (size_t)n);
             k = *(const int *)(st + o_cnt);
+            ctx->env_last_branch = RF_ENV_BRANCH_GRAPH;
         }
     } else {
         // the step's flags and rewards are final after the first half; the count sizes the partial render
@@ -1162,12 +1174,20 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             rc = env_step_end(ctx, host_pool, k, host_obs);
         if (rc != RF_OK)
             return rc;
+        ctx->env_last_branch = RF_ENV_BRANCH_COUNT_SIZED;
     }
     ctx->env_steps += 1;
     ctx->env_scene_len = k > 0 ? k : n;
     ctx->env_last_partial = k > 0;
     if (host_n_reset)
         *host_n_reset = k;
+    return RF_OK;
+}
+
+int rf_env_last_step_branch(rf_ctx *ctx, int *branch)
+{
+    RF_REQUIRE(ctx != nullptr && branch != nullptr, "rf_env_last_step_branch: NULL argument");
+    *branch = ctx->env_last_branch;
     return RF_OK;
 }
 

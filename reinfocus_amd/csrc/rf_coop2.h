@@ -100,9 +100,8 @@ __device__ __forceinline__ uint32_t any_u32()
 // the number of stragglers the block had (block-uniform).
 template <int DIM>
 __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
-                                            uint32_t (&w)[kSets][6])
+                                            uint32_t (&w)[kSets][6], int tid)
 {
-    int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
     uint4 *const state = lds.state[parity];
     unsigned long long ballot[kSets];
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
                 }
             }
         }
-        coop_finish2<2>(lds, 0, need, g, w);
+        coop_finish2<2>(lds, 0, need, g, w, tid);
 
         AxisPre pre[kSets];
 #pragma unroll
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         // whose tile lies inside the target has ~366 such lanes for 256 entries, and the rest would
         // finish in place.  So a block switches to two in-wave attempts when its list overflowed
         // on the previous sample, and back when it would fit again with one.
-        const int stragglers = coop_finish2<3>(lds, 1, need, g, w);
+        const int stragglers = coop_finish2<3>(lds, 1, need, g, w, tid);
         if (sphere_trips == kCoopTrips2 && stragglers > kCoopCap + RF_ADAPT_ON)
             sphere_trips = kCoopTrips2 + 1;
         else if (sphere_trips != kCoopTrips2 && 2 * stragglers < kCoopCap + RF_ADAPT_OFF)

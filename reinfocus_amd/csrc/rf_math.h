@@ -61,6 +61,9 @@ RF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s)
 #ifndef RF_SHL64
 #define RF_SHL64 1
 #endif
+#ifndef RF_BITOP3
+#define RF_BITOP3 0
+#endif
 
 // result = s0 + s1 (as two words), then the xoroshiro128+ 55/14/36 state update:
 // one v_lshl_add_u64 for the sum, v_alignbit_b32 funnel shifts for everything else
@@ -85,8 +88,14 @@ RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
 #else
     const uint32_t sh_lo = x_lo << 14, sh_hi = funnel_r(x_hi, x_lo, 18);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && RF_BITOP3
+    // gfx950's three-input boolean op as a three-way xor (truth table 0x96): one instruction per word
+    g.a_lo = __builtin_amdgcn_bitop3_b32(ro_lo, x_lo, sh_lo, 0x96);
+    g.a_hi = __builtin_amdgcn_bitop3_b32(ro_hi, x_hi, sh_hi, 0x96);
+#else
     g.a_lo = ro_lo ^ x_lo ^ sh_lo;
     g.a_hi = ro_hi ^ x_hi ^ sh_hi;
+#endif
     // rotl(s1, 36) == rotl(swap halves, 4)
     g.b_hi = funnel_r(x_lo, x_hi, 28);
     g.b_lo = funnel_r(x_hi, x_lo, 28);

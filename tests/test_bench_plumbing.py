@@ -73,6 +73,63 @@ def test_a_failing_rank_fails_the_launch():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+def _children_of(pid):
+    try:
+        return [int(c) for c in open(f"/proc/{pid}/task/{pid}/children").read().split()]
+    except OSError:
+        return []
+
+
+def _alive(pid):
+    try:
+        return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_a_terminated_launcher_takes_its_ranks_with_it():
+    """The driver may end `python bench.py --gpus N` with SIGTERM (a timeout): the launcher must not
+    leave ranks behind holding GPUs.  It ends them by PID and exits with 128 + SIGTERM."""
+    import signal
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    parent = subprocess.Popen([sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "100000",
+                               "--warmup", "0"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        deadline = time.monotonic() + 120
+        children = []
+        while len(children) < 2 and time.monotonic() < deadline:
+            children = _children_of(parent.pid)
+            time.sleep(0.1)
+        assert len(children) == 2, children
+        time.sleep(1.0)
+        parent.send_signal(signal.SIGTERM)
+        assert parent.wait(timeout=60) == 128 + signal.SIGTERM
+        deadline = time.monotonic() + 20
+        while any(_alive(c) for c in children) and time.monotonic() < deadline:
+            time.sleep(0.1)
+        assert not any(_alive(c) for c in children), "ranks survived their launcher"
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+
+
+def test_a_rank_that_ignores_sigterm_is_killed():
+    """Rank 1 dies before the rendezvous, rank 0 hangs and ignores SIGTERM: the launcher waits 10 s,
+    terminates, and after the grace period kills -- it must not wait for ever."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(REINFOCUS_BENCH_FAIL_EARLY_RANK="1", REINFOCUS_BENCH_HANG_RANK="0")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "2", "--warmup", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert "ending ranks [0]" in out.stderr
+    assert time.monotonic() - t0 < 120
+
+
 def test_parent_launcher_never_loads_the_hip_library():
     """The launching parent must not initialise the GPU (a process that has may not hand over to
     others on this pool): launch_ranks is reached before reinfocus_amd._native is imported."""

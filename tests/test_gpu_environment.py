@@ -95,31 +95,48 @@ def test_vector_environment_steps_and_auto_resets(oracle):
     env.close()
 
 
+# rf_env_step has three branches (rf_abi.hip): small configurations enqueue the whole step with one
+# host synchronisation and, from their second step on, replay it as one hipGraph ("graph"); the same
+# without the graph ("one-sync"); large configurations -- the benchmarked 4096 x 256 x 256 one among
+# them -- synchronise once mid-step and size the auto-reset launch by the count ("count-sized":
+# rf_env_step_begin + rf_env_step_end).  The context reads the knobs at rf_create.
+STEP_BRANCHES = {"graph": {}, "one-sync": {"REINFOCUS_ENV_GRAPH": "0"},
+                 "count-sized": {"REINFOCUS_ENV_ONE_SYNC_MAX": "0"}}
+
+
+@pytest.mark.parametrize("branch", list(STEP_BRANCHES))
 @pytest.mark.parametrize("n,height,spp,steps", [(64, 32, 4, 45), (300, 16, 2, 30)])
-def test_device_resident_step_equals_host_harness(n, height, spp, steps):
+def test_device_resident_step_equals_host_harness(n, height, spp, steps, branch, monkeypatch):
     """rf_env_* (transformer, enders, scene packing, normaliser, rewards, auto-reset on the
     GPU) against the numpy harness: identical observations, rewards, flags and states for
-    the same seeds and actions, step by step, including the partial auto-reset renders."""
+    the same seeds and actions, step by step, including the partial auto-reset renders -- on
+    every branch of rf_env_step."""
     from reinfocus_amd.environments import harness
 
     kw = dict(num_envs=n, frame_height=height, samples_per_pixel=spp, seed=11, device=0)
     host = harness.VectorDiscreteSteps(**kw)
+    for name, value in STEP_BRANCHES[branch].items():
+        monkeypatch.setenv(name, value)
     dev = harness.DeviceVectorDiscreteSteps(**kw)
+    for name in STEP_BRANCHES[branch]:
+        monkeypatch.delenv(name)
     o_h, _ = host.reset()
     o_d, _ = dev.reset()
     assert o_d.dtype == np.float32 and np.array_equal(o_h, o_d)
     assert np.array_equal(host._state, dev._state)
     rng = np.random.default_rng(5)
     resets = 0
-    for _ in range(steps):
+    for step in range(steps):
         actions = rng.integers(0, 13, n)
-        oh, rh, th, ch, _ = host.step(actions)
-        od, rd, td, cd, _ = dev.step(actions)
+        oh, rh, th, ch, _info = host.step(actions)
+        od, rd, td, cd, _info = dev.step(actions)
         assert np.array_equal(oh, od)
         assert rd.dtype == np.float64 and np.array_equal(rh, rd)
         assert np.array_equal(th, td) and np.array_equal(ch, cd)
         assert np.array_equal(host._state, dev._state)
         resets += int(ch.sum())
+        # (a graph is captured from the second step on, when every buffer has its final size)
+        assert dev._ctx.env_last_step_branch() == ("one-sync" if branch == "graph" and step == 0 else branch)
     assert resets > 0
     # both initializers consumed the same number of draws
     assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state

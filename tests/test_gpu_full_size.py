@@ -146,3 +146,44 @@ def test_first_hip_config(native, oracle):
     assert np.array_equal(ctx.get_states(), st)
     assert np.allclose(ctx.focus(n, h, h), oracle.focus_values(want, n_threads=16), rtol=1e-12, atol=0)
     ctx.close()
+
+
+@pytest.mark.parametrize("n,h,spp,branch", [(4096, 256, 16, "count-sized"), (128, 512, 64, "graph")])
+def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, branch):
+    """The object bench.py measures, at the sizes it is measured at (BASELINE configs[2] and the
+    per-GPU share of configs[4]): harness.DeviceVectorDiscreteSteps -- whose rf_env_step takes the
+    count-sized branch at the headline size (rf_env_step_begin, one host round trip,
+    rf_env_step_end; 128 environments of 512 x 512 are few enough blocks for the one-sync / hipGraph
+    schedule) -- against harness.VectorDiscreteSteps, the reference's numpy glue
+    (environments/vector_environment.py:104-164) around rf_render / rf_focus, which the tests above
+    and tests/test_gpu_parity.py pin to the oracle.  With a time limit of 4 steps the diverging rule
+    ends some environments in step 3 (a partial render of a few), the time limit the rest in step 4
+    (a partial render of most), and from then on the episodes are out of step with each other;
+    observations, rewards, flags and states must be identical bit for bit over 7 steps, and both
+    initializers must have consumed the same draws."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(max_episode_steps=4, num_envs=n, frame_height=h, samples_per_pixel=spp, seed=3, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    o_h, _ = host.reset()
+    o_d, _ = dev.reset()
+    assert np.array_equal(o_h, o_d) and np.array_equal(host._state, dev._state)
+    rng = np.random.default_rng(17)
+    ended = []
+    for step in range(7):
+        actions = rng.integers(0, 13, n)
+        want, got = host.step(actions), dev.step(actions)
+        assert dev._ctx.env_last_step_branch() == ("one-sync" if branch == "graph" and step == 0 else branch)
+        for a, b in zip(want[:4], got[:4]):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert np.array_equal(host._state, dev._state)
+        ended.append(int(got[3].sum()))
+    # steps 1-2: nobody can have ended; step 3: only the diverging rule; step 4: everybody else
+    assert ended[:2] == [0, 0] and 0 < ended[2] < n and ended[2] + ended[3] == n and 0 < ended[6] < n
+    assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state
+    # the RNG states both renderers hold are the same 16 B x n x h x h (spot-checked at both ends)
+    for first in (0, (n - 1) * h * h):
+        assert np.array_equal(host._renderer._ctx.get_states(first, h * h), dev._ctx.get_states(first, h * h))
+    host.close()
+    dev.close()
