@@ -277,6 +277,7 @@ def roofline_from_profile(profile, pixels_per_launch):
             "inst_wait_share": e.get("inst_wait_share"),      # SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
             "salu_per_valu": e.get("salu_per_valu"),          # SQ_INSTS_SALU / SQ_INSTS_VALU
             "valu_insts_per_64_pixels": e["valu_insts_per_wave"] * 64.0 / float(e.get("pixels_per_wave", 64)),
+            "pixels_from": e.get("pixels_from", "SQ_WAVES x pixels per wave (padded lanes included)"),
             "from_committed_profile": profile["file"] is not None,
             "measured_by": ("profiles/" + profile["file"] if profile["file"] else
                             "rocprofv3 --pmc child runs of this invocation"),
@@ -300,7 +301,15 @@ def derive_pmc(e, kernel):
         e["hbm_read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2  # KiB; gfx950 counts wide reads at half
     if "WRITE_SIZE" in e:
         e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
-    e["pixels_per_wave"] = 192 if "render_kernel_coop2" in kernel else 64
+    # pixels: what the profiled process really rendered with this kernel (rf_pixels_rendered, "pixels" in
+    # the totals); the fallback -- waves x pixels per wave -- counts the padded lanes of partial tiles as
+    # pixels and is only right for frames that are a whole number of tiles and the default kSets = 3
+    if e.get("pixels") and e.get("SQ_WAVES"):
+        e["pixels_per_wave"] = e["pixels"] / e["SQ_WAVES"]
+        e["pixels_from"] = "rf_pixels_rendered of the profiled run"
+    else:
+        e["pixels_per_wave"] = 192 if "render_kernel_coop2" in kernel else 64
+        e["pixels_from"] = "SQ_WAVES x pixels per wave (padded lanes included)"
     if e.get("SQ_WAVES") and "SQ_INSTS_VALU" in e:
         e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
     if e.get("GRBM_GUI_ACTIVE") and e.get("SQ_INSTS_VALU"):
@@ -347,6 +356,11 @@ def measure_pmc(args, kernel):
             for row in csv.DictReader(open(files[0])):
                 if kernel_key(row["Kernel_Name"]) == kernel_key(kernel):
                     totals[row["Counter_Name"]] = totals.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+            if lines and "pixels" not in totals:  # every pass renders the same pixels (same seeds)
+                child_line = json.loads(lines[-1])
+                if child_line.get("render_pixels_by_kernel", {}).get(kernel_key(kernel)):
+                    totals["pixels"] = float(child_line["render_pixels_by_kernel"][kernel_key(kernel)])
         if not totals.get("SQ_WAVES"):
             return None, f"no counters for {kernel}"
         return {"file": None, "commit": None, "entry": derive_pmc(totals, kernel),
@@ -355,6 +369,26 @@ def measure_pmc(args, kernel):
         return None, f"rocprofv3: {error}"
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def baseline_config_name(envs_per_gpu, frame, spp, n_gpus):
+    """Which BASELINE.json configuration a run is (so that the line never claims another one's name)."""
+    total = envs_per_gpu * n_gpus
+    if (frame, spp) == (256, 16) and envs_per_gpu == 4096:
+        return ("BASELINE.json configs[2]" if n_gpus == 1 else
+                "BASELINE.json configs[3]" if n_gpus == 8 else
+                f"BASELINE.json configs[2] per GPU, weak-scaled to {n_gpus} GPUs (configs[3] is the 8-GPU point)")
+    if (frame, spp) == (512, 64) and total == 1024 and n_gpus == 8:
+        return "BASELINE.json configs[4]"
+    if (frame, spp) == (512, 64) and envs_per_gpu == 128:
+        return f"per-GPU share of BASELINE.json configs[4] (1024 envs over 8 GPUs) on {n_gpus} GPU(s)"
+    if (envs_per_gpu, frame, spp, n_gpus) == (256, 128, 4, 1):
+        return "BASELINE.json configs[1]"
+    if (envs_per_gpu, frame, spp, n_gpus) == (1, 64, 1, 1):
+        return "BASELINE.json configs[0] on the GPU path"
+    if (frame, spp) == (300, 100):
+        return "not a BASELINE.json configuration: the reference's default frame size and sample count"
+    return "not a BASELINE.json configuration"
 
 
 def shard_plan(rank, envs_per_gpu, frame):
@@ -480,12 +514,15 @@ def main(argv=None):
         from reinfocus_amd import _native
         from reinfocus_amd.environments import harness
 
-        if _native.device_count() < (args.gpus if args.sharded_env else 1):
+        # REINFOCUS_BENCH_DEVICE: every rank / every shard on that one device (rehearsals on a 1-GPU box)
+        pinned = os.environ.get("REINFOCUS_BENCH_DEVICE")
+        if _native.device_count() < (args.gpus if args.sharded_env and pinned is None else 1):
             raise SystemExit("bench.py needs a GPU per rank: reinfocus_amd has no CPU fallback")
-        device = int(os.environ.get("REINFOCUS_BENCH_DEVICE", ranks.local_rank))
+        device = int(pinned) if pinned is not None else ranks.local_rank
         common = dict(num_envs=n_here, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank)
         if args.sharded_env:
-            env = harness.ShardedVectorDiscreteSteps(devices=list(range(args.gpus)), **common)
+            devices = [int(pinned)] * args.gpus if pinned is not None else list(range(args.gpus))
+            env = harness.ShardedVectorDiscreteSteps(devices=devices, **common)
             contexts = [shard.ctx for shard in env._shards]
         else:
             env_cls = harness.DeviceVectorDiscreteSteps if args.env == "device" else harness.VectorDiscreteSteps
@@ -493,6 +530,7 @@ def main(argv=None):
             contexts = [env._ctx if args.env == "device" else env._renderer._ctx]
         ctx = contexts[0]
         env.reset()
+        pixels_before_first_step = _native.pixels_rendered()
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
     def one_step():
@@ -525,6 +563,8 @@ def main(argv=None):
     total_resets = ranks.reduce(resets, "SUM")
 
     timing = ctx.timing_read() if env is not None and not args.no_kernel_timing else None
+    all_kernel_ms = (sum(sum(c.timing_read()[k] for k in ("render_ms", "focus_ms")) for c in contexts)
+                     if timing is not None else None)
     n_gpus = args.gpus if args.sharded_env else ranks.world
     total_envs = n_local * n_gpus
     value = total_envs * args.steps / elapsed if env is not None else None
@@ -546,7 +586,7 @@ def main(argv=None):
             "data": "synthetic" if env is not None else "none (plumbing test, not a measurement)",
             "config": {
                 "workload": f"DiscreteSteps-v0 vector env, {n_local} envs/GPU x {frame}x{frame} x {spp} spp "
-                            f"(BASELINE.json configs[2]; weak-scaled per GPU = configs[3])",
+                            f"({baseline_config_name(n_local, frame, spp, n_gpus)})",
                 "envs_per_gpu": n_local,
                 "total_envs": total_envs,
                 "frame": frame,
@@ -558,6 +598,11 @@ def main(argv=None):
                 "env_glue": "device-resident (rf_env_step)" if args.env == "device" else "host numpy (harness)",
             },
         }
+        if env is not None:
+            # every render launch of this process used the same kernel instance when the 13-environment
+            # extrema render (cached_focus_extrema: same frame size and sample count) is among them
+            out["render_pixels_by_kernel"] = {kernel_key(ctx.render_kernel_name()): _native.pixels_rendered()}
+            out["render_pixels_before_first_step"] = pixels_before_first_step
         if timing is not None:
             # full renders + the partial auto-reset renders of rank 0 (of shard 0 with --sharded-env)
             resets_here = resets if not args.sharded_env else resets / n_gpus
@@ -606,6 +651,16 @@ def main(argv=None):
                 "launches": timing["focus_launches"],
             }
             out["kernel_time_frac_of_wall"] = (render_s + focus_s) / elapsed_local
+            if args.sharded_env:
+                # with every shard on one device (REINFOCUS_BENCH_DEVICE) the kernels serialise, and what is
+                # left of the wall time is the host side of the threaded object
+                out["sharded_env"] = {
+                    "contexts": len(contexts), "devices": env.devices,
+                    "kernel_ms_per_step_all_contexts": all_kernel_ms / args.steps,
+                    "wall_ms_per_step": 1000.0 * elapsed_local / args.steps,
+                    "host_ms_per_step_if_one_device": (1000.0 * elapsed_local - all_kernel_ms) / args.steps
+                    if len(set(env.devices)) == 1 else None,
+                }
         if env is not None and not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(frame, spp, args.cpu_baseline_envs, ctx.device)
     if env is not None:

@@ -114,6 +114,11 @@ int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *ho
  * No reference counterpart (bench.py reports it next to the roofline figures). */
 const char *rf_render_kernel_name(rf_ctx *ctx);
 
+/* Pixels every render launch of this process (all contexts) was made for, n * h * w each, since the
+ * library was loaded.  No reference counterpart: bench.py divides the PMC totals of a profiled run by
+ * it, so that per-pixel figures count the pixels really rendered (not waves x pixels per wave). */
+unsigned long long rf_pixels_rendered(void);
+
 /* Blocks until everything enqueued on the ctx's stream has finished. */
 int rf_synchronize(rf_ctx *ctx);
 
@@ -195,10 +200,34 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
  *   rf_env_step_end     those k environments take host_pool float32[k][2] in index order and are
  *                       rendered and scored again (vector_environment.py:137-151); observations
  *                       float32[n][4] of all environments.  host_pool may be NULL when k == 0.
- * rf_env_step == begin + end with the pool's first k rows. */
+ * rf_env_step == begin + end with the pool's first k rows -- on ONE context.  Several contexts that
+ * share an environment range (harness.ShardedVectorDiscreteSteps) are not bit-equal to one context
+ * holding all of it after the first auto-reset: each context's partial render indexes RNG states from
+ * its own base, where a single context (like the reference, graphics/render.py:217 on
+ * vector_environment.py:144's compacted rows) indexes the compacted set of ALL ended environments
+ * from state 0 (the sharded environment's exact mode gathers them instead).
+ *   rf_env_step_abort   drops an open two-phase step (after a failure on another shard): the
+ *                       environments that ended stay un-reset and rf_env_reset must come next. */
 int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rewards, uint8_t *host_truncated,
                       int *host_n_reset);
 int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs);
+int rf_env_step_abort(rf_ctx *ctx);
+
+/* Exact mode of an environment sharded over several contexts (opt-in; harness.ShardedVectorDiscreteSteps
+ * exact=True).  On one device the partial render of an auto-reset indexes RNG states from 0 over the
+ * compacted rows of ALL environments that ended (vector_environment.py:144 -> state_observer.py:377-381
+ * -> render.py:217), i.e. compacted row r draws from the states of environment slot r.  To reproduce
+ * that, row r is rendered by the context that owns slot r, whichever context the ended environment
+ * lives on, and the focus value travels back through the host:
+ *   rf_env_render_states   packs host_states float32[k][2] (target, focus plane) as compacted rows
+ *                          0..k-1, renders them at the environment's frame size / spp from THIS context's
+ *                          RNG state 0 and scores them: host_focus float64[k].  Afterwards the context's
+ *                          renderer holds that set (rf_env_render draws it), as the reference's does.
+ *   rf_env_step_end_given  rf_env_step_end without the render: this context's k ended environments take
+ *                          host_pool float32[k][2] in index order, and their reset observations are built
+ *                          from host_focus float64[k]. */
+int rf_env_render_states(rf_ctx *ctx, int k, const float *host_states, double *host_focus);
+int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *host_focus, float *host_obs);
 
 /* Renders the scene set the environment uploaded last -- all n environments after a step in which
  * none ended, otherwise only the k that were reset, exactly what the reference's shared

@@ -27,11 +27,24 @@ class CamStatic(ctypes.Structure):
 
 
 def build(force=False):
-    """Compiles the oracle with gcc (no FMA contraction)."""
+    """Compiles the oracle with gcc (no FMA contraction) where the sources are edited.  On the GPU box
+    (/dev/kfd exists) nothing is compiled: the library that travelled with the checkout must be the
+    build of the sources next to it (its .srchash, written by the Makefile, must still match)."""
+    if os.path.exists("/dev/kfd"):
+        import hashlib
+
+        stamp = _SO + ".srchash"
+        assert os.path.exists(_SO) and os.path.exists(stamp), f"{_SO} (+ .srchash) missing: run __graft_entry__.build()"
+        for line in open(stamp).read().splitlines():
+            digest, path = line.split()
+            now = hashlib.sha256(open(os.path.join(_HERE, path), "rb").read()).hexdigest()
+            assert now == digest, f"{_SO} is stale: {path} changed since it was built"
+        return _SO
     src = os.path.join(_HERE, "rf_oracle.c")
     if (
         force
         or not os.path.exists(_SO)
+        or not os.path.exists(_SO + ".srchash")
         or os.path.getmtime(_SO) < os.path.getmtime(src)
         or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "rf_oracle.h"))
     ):

@@ -50,12 +50,16 @@ SYMBOLS = (
     "rf_env_step",
     "rf_env_step_begin",
     "rf_env_step_end",
+    "rf_env_step_abort",
+    "rf_env_render_states",
+    "rf_env_step_end_given",
     "rf_env_get_states",
     "rf_env_scene_len",
     "rf_env_render",
     "rf_env_get_counters",
     "rf_env_last_step_branch",
     "rf_render_kernel_name",
+    "rf_pixels_rendered",
 )
 
 
@@ -134,6 +138,9 @@ def load():
     lib.rf_env_step.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
     lib.rf_env_step_begin.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
     lib.rf_env_step_end.argtypes = [vp, vp, vp]
+    lib.rf_env_step_abort.argtypes = [vp]
+    lib.rf_env_render_states.argtypes = [vp, i32, vp, vp]
+    lib.rf_env_step_end_given.argtypes = [vp, vp, vp, vp]
     lib.rf_env_get_states.argtypes = [vp, vp]
     lib.rf_env_scene_len.argtypes = [vp, ctypes.POINTER(i32)]
     lib.rf_env_render.argtypes = [vp, i32, i32, vp]
@@ -141,6 +148,8 @@ def load():
     lib.rf_env_last_step_branch.argtypes = [vp, ctypes.POINTER(i32)]
     lib.rf_render_kernel_name.restype = ctypes.c_char_p
     lib.rf_render_kernel_name.argtypes = [vp]
+    lib.rf_pixels_rendered.restype = ctypes.c_ulonglong
+    lib.rf_pixels_rendered.argtypes = []
     _lib = lib
     return lib
 
@@ -160,6 +169,11 @@ def device_count():
     n = ctypes.c_int(0)
     _check(load().rf_device_count(ctypes.byref(n)))
     return n.value
+
+
+def pixels_rendered():
+    """Pixels all render launches of this process were made for (rf_pixels_rendered)."""
+    return int(load().rf_pixels_rendered())
 
 
 def default_device():
@@ -309,6 +323,30 @@ class Context:
         obs = np.empty((n, 4), dtype=np.float32)
         _check(self._lib.rf_env_step_end(self._h, _ptr(pool_rows) if len(pool_rows) else None, _ptr(obs)))
         return obs
+
+    def env_render_states(self, states):
+        """Exact mode of a sharded environment: float32[k, 2] states rendered and scored as compacted rows
+        0..k-1 from this context's RNG state 0; float64[k] focus values."""
+        states = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, 2)
+        focus = np.empty(len(states), dtype=np.float64)
+        _check(self._lib.rf_env_render_states(self._h, len(states), _ptr(states), _ptr(focus)))
+        return focus
+
+    def env_step_end_given(self, pool_rows, focus):
+        """Second half of a two-phase step whose reset renders happened elsewhere: observations."""
+        n = self._env_n
+        pool_rows = np.ascontiguousarray(pool_rows, dtype=np.float32).reshape(-1, 2)
+        focus = np.ascontiguousarray(focus, dtype=np.float64).reshape(-1)
+        assert len(focus) == len(pool_rows)
+        obs = np.empty((n, 4), dtype=np.float32)
+        some = len(pool_rows) > 0
+        _check(self._lib.rf_env_step_end_given(self._h, _ptr(pool_rows) if some else None,
+                                               _ptr(focus) if some else None, _ptr(obs)))
+        return obs
+
+    def env_step_abort(self):
+        """Drops an open two-phase step (another shard failed): env_reset must come next."""
+        _check(self._lib.rf_env_step_abort(self._h))
 
     def env_scene_len(self):
         n = ctypes.c_int(0)

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -29,6 +30,7 @@
 namespace {
 
 thread_local std::string g_err;
+std::atomic<unsigned long long> g_pixels_rendered{0}; // every pixel any render kernel of this process was launched for
 
 void set_err(const char *fmt, ...)
 {
@@ -111,6 +113,7 @@ struct rf_ctx {
     int env_pending = -1; // >= 0: rf_env_step_begin ran and that many environments wait for rf_env_step_end
     bool env_graph_fail_once = false; // REINFOCUS_ENV_GRAPH_FAIL=1 (tests): the first instantiation "fails"
     int env_last_branch = RF_ENV_BRANCH_NONE; // rf_env_last_step_branch
+    bool env_needs_reset = false; // rf_env_step_abort dropped a half-finished step
     long env_one_sync_max = 65536; // blocks of a full render up to which rf_env_step runs without the mid-step round
                                    // trip (REINFOCUS_ENV_ONE_SYNC_MAX; tests set 0 to reach the count-sized branch at small sizes)
     const char *render_kernel = "none"; // the render kernel the last launch used (rf_render_kernel_name)
@@ -591,6 +594,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         }
     }
     RF_HIP(hipGetLastError());
+    g_pixels_rendered += (unsigned long long)n * (unsigned long long)a.hw;
     if (ctx->ev_render.size() > 512)
         return drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
     return RF_OK;
@@ -723,6 +727,8 @@ int rf_step(rf_ctx *ctx, int n, int h, int w, int spp, int gray_mode, double *ho
 }
 
 const char *rf_render_kernel_name(rf_ctx *ctx) { return ctx ? ctx->render_kernel : "none"; }
+
+unsigned long long rf_pixels_rendered(void) { return g_pixels_rendered.load(); }
 
 int rf_synchronize(rf_ctx *ctx)
 {
@@ -956,6 +962,7 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     RF_REQUIRE(ctx->env_ready, "rf_env_reset: rf_env_configure first");
     RF_HIP(hipSetDevice(ctx->device));
     ctx->env_pending = -1;
+    ctx->env_needs_reset = false;
     const rf_env_config &h = ctx->env_host;
     const int n = h.n, fh = h.frame_height;
     RF_HIP(hipMemcpyAsync(ctx->env.state, host_states, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1084,6 +1091,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                "rf_env_step: NULL argument");
     RF_REQUIRE(ctx->env_ready, "rf_env_step: rf_env_configure first");
     RF_REQUIRE(ctx->env_pending < 0, "rf_env_step: a two-phase step is open (rf_env_step_end first)");
+    RF_REQUIRE(!ctx->env_needs_reset, "rf_env_step: a step was aborted (rf_env_reset first)");
     RF_HIP(hipSetDevice(ctx->device));
     const rf_env_config &h = ctx->env_host;
     const int n = h.n;
@@ -1198,6 +1206,7 @@ int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rew
                "rf_env_step_begin: NULL argument");
     RF_REQUIRE(ctx->env_ready, "rf_env_step_begin: rf_env_configure first");
     RF_REQUIRE(ctx->env_pending < 0, "rf_env_step_begin: the previous step was not finished (rf_env_step_end)");
+    RF_REQUIRE(!ctx->env_needs_reset, "rf_env_step_begin: a step was aborted (rf_env_reset first)");
     RF_HIP(hipSetDevice(ctx->device));
     drop_env_graph(ctx);
     const rf_env_config &h = ctx->env_host;
@@ -1229,6 +1238,71 @@ int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs)
         ctx->env_last_partial = k > 0;
     }
     return rc;
+}
+
+int rf_env_render_states(rf_ctx *ctx, int k, const float *host_states, double *host_focus)
+{
+    RF_REQUIRE(ctx != nullptr && host_states != nullptr && host_focus != nullptr, "rf_env_render_states: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_render_states: rf_env_configure first");
+    const rf_env_config &h = ctx->env_host;
+    RF_REQUIRE(k > 0 && k <= h.n, "rf_env_render_states: k=%d outside [1, %d]", k, h.n);
+    RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
+    const int fh = h.frame_height;
+    RF_HIP(hipMemcpyAsync(ctx->d_pool, host_states, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rf::env_pack_rows_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const float *)ctx->d_pool, k);
+    int rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+    if (rc == RF_OK)
+        rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+    if (rc != RF_OK)
+        return rc;
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(host_focus, ctx->d_var, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_scene_len = k; // the renderer now holds this compacted set (what rf_env_render would draw)
+    ctx->env_last_partial = true;
+    return RF_OK;
+}
+
+int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *host_focus, float *host_obs)
+{
+    RF_REQUIRE(ctx != nullptr && host_obs != nullptr, "rf_env_step_end_given: NULL argument");
+    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0, "rf_env_step_end_given: rf_env_step_begin first");
+    const int k = ctx->env_pending;
+    RF_REQUIRE(k == 0 || (host_pool != nullptr && host_focus != nullptr),
+               "rf_env_step_end_given: %d environments ended but host_pool / host_focus is NULL", k);
+    RF_HIP(hipSetDevice(ctx->device));
+    ctx->env_pending = -1;
+    const int n = ctx->env_host.n;
+    if (k > 0) {
+        RF_REQUIRE(k <= ctx->focus_cap, "rf_env_step_end_given: focus buffer smaller than %d", k);
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+        // the focus values were measured elsewhere: they take the place launch_focus would have filled
+        RF_HIP(hipMemcpyAsync(ctx->d_var, host_focus, (size_t)k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool, rf::kEnvResetApply);
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
+                           ctx->env, (const double *)ctx->d_var);
+        RF_HIP(hipGetLastError());
+    }
+    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_steps += 1;
+    return RF_OK;
+}
+
+int rf_env_step_abort(rf_ctx *ctx)
+{
+    RF_REQUIRE(ctx != nullptr, "rf_env_step_abort: ctx is NULL");
+    RF_REQUIRE(ctx->env_ready, "rf_env_step_abort: rf_env_configure first");
+    if (ctx->env_pending >= 0) {
+        // the episode bookkeeping of the environments that ended is half way through a step: only a
+        // reset makes the environment usable again, and rf_env_step / _begin say so until then
+        ctx->env_pending = -1;
+        ctx->env_needs_reset = true;
+    }
+    return RF_OK;
 }
 
 int rf_env_scene_len(rf_ctx *ctx, int *n_envs)

@@ -212,6 +212,17 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
             s.rect2[2 * r] = __builtin_bit_cast(float, kSkipEnvBits);
 }
 
+// Scene of k given states as rows 0..k-1 of the compacted set (cam_dyn2 / rect2): the packing half of
+// FocusObserver.observe(new_state, indices) (state_observer.py:377-378) for rows that belong to
+// environments of OTHER contexts -- the exact mode of a sharded environment renders compacted row r
+// on the context that owns the RNG states of pixel indices [r h w, (r + 1) h w) (render.py:217).
+__global__ void env_pack_rows_kernel(EnvConfig c, EnvState s, const float *states, int k)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < k)
+        pack_scene(c, states[2 * r], states[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+}
+
 // observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the
 // rewarder's reset (vector_environment.py:144-148)
 __global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values)

@@ -396,8 +396,10 @@ __global__ __launch_bounds__(kBlock, 5) void render_general_kernel(GeneralArgs a
         b8 = (uint8_t)(cb * a.scale);
     }
     // a full block whose first byte is dword-aligned goes through LDS; anything else stores bytes
+    // (the ADDRESS decides: a.frames is the chunk's base, which for the chunks after the first --
+    // 65535 environments each -- is itself only 4-byte aligned when h * w * 3 is a multiple of 4)
     const size_t first_byte = ((size_t)e * a.hw + p0) * 3;
-    const bool staged = p0 + kBlock <= a.hw && (first_byte & 3) == 0; // block-uniform
+    const bool staged = p0 + kBlock <= a.hw && (reinterpret_cast<uintptr_t>(a.frames + first_byte) & 3) == 0; // block-uniform
     if (staged) {
         uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
         sb[threadIdx.x * 3 + 0] = r8;

@@ -545,13 +545,30 @@ def split_environments(num_envs, shards):
     return [(int(f), int(c)) for f, c in zip(firsts, counts)]
 
 
+class _ShardSet:
+    """What HistoryVisualizer needs from "the renderer" and "the ender" of a sharded environment
+    (episode_visualizer.py:197, :268): every shard draws the scene set it uploaded last -- each
+    behaves like the reference's one shared renderer for its own environment range -- and the rows
+    are stacked in shard order."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def render(self, frame_height):
+        return np.concatenate(self._env._each(lambda shard: np.asarray(shard.render(frame_height))))
+
+    def status(self, index):
+        g, local = self._env._locate(index)
+        return self._env._shards[g].status(local)
+
+
 class ShardedVectorDiscreteSteps(_VectorEnvBase):
     """DeviceVectorDiscreteSteps over several GPUs of one node (the
     reference has no counterpart: vector_environment.py:104-164 steps all environments on one
     device).  Environments are independent, so device g owns the contiguous range
-    [first_g, first_g + n_g) -- one rf_ctx and one host thread per device (ctypes releases the
-    GIL), no device-to-device traffic, the host concatenates observations / rewards / flags
-    (8 + 16 + 1 bytes per environment).
+    [first_g, first_g + n_g) -- one rf_ctx and one host thread per device (a single-worker executor
+    each; ctypes releases the GIL), no device-to-device traffic, the host concatenates observations /
+    rewards / flags (8 + 16 + 1 bytes per environment).
 
     RNG states: shard g is seeded at global state index first_state_index + first_g * h * h
     (pixel index = e * h * w + y * w + x, render.py:217), so full renders draw exactly what one
@@ -559,24 +576,36 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
     environment; the r-th environment that ended, in global index order, takes the r-th drawn
     state, as on one device -- which is why a step has two halves (rf_env_step_begin /
     rf_env_step_end): the rows a shard takes depend on how many environments ended before it.
-    Deviation (documented in DESIGN.md section 6): the partial render of an auto-reset re-indexes
-    its RNG states from the shard's own base instead of from the global state 0 of the compacted
-    done set (render.py:217 on vector_environment.py:144's compacted rows), so after the first
-    auto-reset the sharded run and the one-device run are different -- equally valid -- sample
-    paths.  `devices` may name a device more than once (several contexts on one GPU: tests)."""
 
-    metadata = {"render_modes": [], "render_fps": 4}
+    Auto-reset renders.  On one device the partial render indexes RNG states from 0 over the
+    compacted rows of all environments that ended (vector_environment.py:144 -> render.py:217):
+    compacted row r draws from the states of environment slot r.
+     * default: every shard renders its own ended environments from its own state base -- balanced,
+       no traffic, but after the first auto-reset a sharded run and a one-device run are different
+       (equally valid) sample paths (DESIGN.md section 6);
+     * exact=True: row r is rendered by the shard that owns slot r (rf_env_render_states) and the
+       focus value returns through the host to the shard the environment lives on
+       (rf_env_step_end_given): bit-identical to one device through any number of auto-resets, at the
+       price of the first shards rendering everybody's resets.  Meant for tests and reproducibility
+       studies, not for throughput.
+    render_mode="rgb_array": HistoryVisualizer over the shards (each shard's 600 px render advances /
+    re-seeds that shard's RNG states as the reference's single renderer would for its range; the
+    exact mode does not extend to visualised runs).  `devices` may name a device more than once
+    (several contexts on one GPU: tests, rehearsals)."""
+
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
 
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, devices=None, frame_height=300,
-                 samples_per_pixel=100, seed=None, first_state_index=0):
+                 samples_per_pixel=100, seed=None, first_state_index=0, exact=False):
         import concurrent.futures
         import copy
 
         from reinfocus_amd import _native
 
         super().__init__()
-        assert render_mode is None, "the sharded environment has no visualiser (use DeviceVectorDiscreteSteps)"
-        self.render_mode = None
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        self.render_mode = render_mode
+        self.exact = bool(exact)
         self._copy = copy
         if devices is None:
             devices = list(range(_native.device_count()))
@@ -587,36 +616,54 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         self._ranges = split_environments(num_envs, len(devices))
         self._limits = _DeviceShard.ENDS
         self._initializer = _Initializer(self._limits, seed)
-        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(devices),
-                                                           thread_name_prefix="reinfocus-shard")
+        # one thread per shard for the life of the environment: a shard's context is only ever
+        # touched from its own thread
+        self._threads = [concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"reinfocus-shard{g}")
+                         for g in range(len(devices))]
         pixels = frame_height * frame_height
         self._shards = []
         try:
-            futures = [self._pool.submit(_DeviceShard, count, max_episode_steps, frame_height, samples_per_pixel,
-                                         device, first_state_index + first * pixels)
-                       for device, (first, count) in zip(devices, self._ranges)]
+            futures = [thread.submit(_DeviceShard, count, max_episode_steps, frame_height, samples_per_pixel,
+                                     device, first_state_index + first * pixels)
+                       for thread, device, (first, count) in zip(self._threads, devices, self._ranges)]
             for future in futures:
                 try:
                     self._shards.append(future.result())
                 except Exception:
                     for other in futures:
-                        if other.done() and other.exception() is None:
+                        try:
                             other.result().ctx.close()
+                        except Exception:
+                            pass
                     raise
         except Exception:
-            self._pool.shutdown(wait=True)
+            for thread in self._threads:
+                thread.shutdown(wait=True)
             raise
         self._action_set = self._shards[0].action_set
         _device_spaces(self, self._action_set, num_envs)
+        self._visualizer = None
+        if render_mode == "rgb_array":  # custom_environments.py:229-238
+            both = _ShardSet(self)
+            self._visualizer = episode_visualizer.HistoryVisualizer(
+                num_envs, TARGET, FOCUS, 1, both, self._limits, ender=both, target_radius=_DeviceShard.TARGET_RADIUS)
+
+    def _submit(self, function, *per_shard):
+        return [thread.submit(function, shard, *(a[g] for a in per_shard))
+                for g, (thread, shard) in enumerate(zip(self._threads, self._shards))]
 
     def _each(self, function, *per_shard):
         """function(shard, *args_g) on every shard's own thread; results in shard order."""
-        futures = [self._pool.submit(function, shard, *(a[g] for a in per_shard))
-                   for g, shard in enumerate(self._shards)]
-        return [f.result() for f in futures]
+        return [f.result() for f in self._submit(function, *per_shard)]
 
     def _slices(self, array):
         return [array[first:first + count] for first, count in self._ranges]
+
+    def _locate(self, index):
+        for g, (first, count) in enumerate(self._ranges):
+            if first <= index < first + count:
+                return g, index - first
+        raise IndexError(index)
 
     @property
     def _state(self):
@@ -627,29 +674,82 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
             self._initializer = _Initializer(self._limits, seed)
         initial = (self._initializer.initialize(self.num_envs) if state is None
                    else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
-        observations = self._each(lambda shard, rows: shard.ctx.env_reset(rows), self._slices(initial))
-        return np.concatenate(observations), {}
+        observations = np.concatenate(self._each(lambda shard, rows: shard.ctx.env_reset(rows), self._slices(initial)))
+        if self._visualizer is not None:
+            self._visualizer.reset(initial, observations)
+        return observations, {}
+
+    def _begin(self, actions):
+        """First half of the step on every shard.  If any shard fails, the shards whose half did run
+        drop it (rf_env_step_abort: they then insist on a reset) and the first error is raised."""
+        futures = self._submit(lambda shard, a: shard.ctx.env_step_begin(a), self._slices(actions))
+        results, errors = [], []
+        for future in futures:
+            try:
+                results.append(future.result())
+            except Exception as error:  # noqa: BLE001 -- re-raised below
+                results.append(None)
+                errors.append(error)
+        if errors:
+            aborts = [thread.submit(shard.ctx.env_step_abort)
+                      for thread, shard, result in zip(self._threads, self._shards, results) if result is not None]
+            for abort in aborts:
+                abort.result()
+            raise errors[0]
+        return results
 
     def step(self, actions):
         actions = np.asarray(actions).reshape(self.num_envs)
+        # every shard validates its slice again, but a bad action must not leave some shards half way
+        # through a step: check all of them before any shard begins
+        if actions.size and (actions.min() < 0 or actions.max() >= len(self._action_set)):
+            raise AssertionError(f"action outside [0, {len(self._action_set)})")
         proposal = self._copy.deepcopy(self._initializer._generator)
         pool = proposal.uniform(self._limits[0], self._limits[1], size=(self.num_envs, 2)).astype(np.float32)
-        firsts = self._each(lambda shard, a: shard.ctx.env_step_begin(a), self._slices(actions))
+        firsts = self._begin(actions)
         ended = [k for _, _, k in firsts]
         starts = np.concatenate([[0], np.cumsum(ended)]).astype(int)
+        total = int(starts[-1])
         rows = [pool[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
-        observations = self._each(lambda shard, r: shard.ctx.env_step_end(r), rows)
-        if starts[-1]:
-            self._initializer.initialize(int(starts[-1]))  # consume exactly the rows that were used
+        if self.exact and total:
+            # compacted row r is rendered where environment slot r's RNG states live
+            spans = [(first, min(first + count, total)) for first, count in self._ranges]
+            renders = [thread.submit(shard.ctx.env_render_states, pool[lo:hi])
+                       for thread, shard, (lo, hi) in zip(self._threads, self._shards, spans) if lo < hi]
+            focus = np.concatenate([r.result() for r in renders])
+            assert len(focus) == total
+            values = [focus[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
+            observations = self._each(lambda shard, r, v: shard.ctx.env_step_end_given(r, v), rows, values)
+        elif self.exact:
+            observations = self._each(lambda shard, r: shard.ctx.env_step_end_given(r, np.zeros(0)), rows)
+        else:
+            observations = self._each(lambda shard, r: shard.ctx.env_step_end(r), rows)
+        if total:
+            self._initializer.initialize(total)  # consume exactly the rows that were used
+        observations = np.concatenate(observations)
         rewards = np.concatenate([r for r, _, _ in firsts])
         truncated = np.concatenate([t for _, t, _ in firsts])
-        return np.concatenate(observations), rewards, np.full(self.num_envs, False), truncated, {}
+        if self._visualizer is not None:  # vector_environment.py:149-156
+            state = self._state
+            if total:
+                self._visualizer.reset(state[truncated], observations[truncated], truncated)
+            self._visualizer.step(state[~truncated], observations[~truncated], ~truncated)
+        return observations, rewards, np.full(self.num_envs, False), truncated, {}
 
     def render(self):
+        """vector_environment.py:166-176."""
+        if self._visualizer is not None:
+            return self._visualizer.visualize()
         return None
 
+    def render_frames(self):
+        """Only the left halves of render(): the 600 px frames every shard's renderer holds."""
+        return _ShardSet(self).render(episode_visualizer.HistoryVisualizer.FRAME)
+
     def close(self):
-        for shard in self._shards:
-            shard.ctx.close()
+        for thread, shard in zip(self._threads, self._shards):
+            thread.submit(shard.ctx.close).result()
         self._shards = []
-        self._pool.shutdown(wait=True)
+        for thread in self._threads:
+            thread.shutdown(wait=True)
+        self._threads = []

@@ -53,6 +53,37 @@ extern "C" int gc_check_sqrt_rcp(unsigned long long out[3])
     return 0;
 }
 
+// approx_pm1 (rf_math.h) builds its candidate from a SUBNORMAL float (the top 23 bits of the draw read
+// as float bits) and one fma: correct only if the device neither flushes f32 subnormals nor rounds
+// the fma.  Every one of the 2^32 high words against the same value computed in float64.
+__global__ void check_approx_pm1_kernel(unsigned long long *bad)
+{
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32);
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t hi = (uint32_t)i;
+        const double want = (double)(hi >> 9) * (1.0 / 4194304.0) - 1.0; // k 2^-22 - 1: 24 bits, exact
+        if (!((double)rf::approx_pm1(hi) == want))
+            ++mine;
+    }
+    if (mine)
+        atomicAdd(bad, mine);
+}
+
+extern "C" int gc_check_approx_pm1(unsigned long long *out)
+{
+    unsigned long long *d_bad;
+    if (hipMalloc((void **)&d_bad, 8) != hipSuccess || hipMemset(d_bad, 0, 8) != hipSuccess)
+        return -1;
+    hipLaunchKernelGGL(check_approx_pm1_kernel, dim3(8192), dim3(256), 0, 0, d_bad);
+    if (hipDeviceSynchronize() != hipSuccess)
+        return -2;
+    if (hipMemcpy(out, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return -3;
+    (void)hipFree(d_bad);
+    return 0;
+}
+
 // ---- probes of the general renderer's float64 library calls (see probe_general.h) ----------
 __global__ void probe_f64_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
 {

@@ -9,6 +9,8 @@ import os
 
 import numpy as np
 import pytest
+
+from tests import helpers
 from numpy import testing
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -170,10 +172,7 @@ def _random_scene(rng, n):
 
 def test_general_kernel_arithmetic_equals_oracle(oracle):
     """rf_general.h compiled for the host (tests/hostsim) on random multi-shape scenes."""
-    import subprocess
-
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
-    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     p = ctypes.c_void_p
     hs.hs_render_general.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p]
     rng = np.random.default_rng(17)
@@ -214,10 +213,7 @@ def test_checker_shortcut_equals_the_literal_sine_sign():
     """rf_general.h checker_sign_general (parity of floor(f * u) away from the checker's edges, the
     real sin next to them) against the reference's expression sin((f * pi) * u) (physics.py:58-62)
     with glibc's sin, on random coordinates and on coordinates at / next to every edge."""
-    import subprocess
-
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
-    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     n = 2_000_000
     rng = np.random.default_rng(3)
@@ -256,10 +252,7 @@ def test_sphere_checker_fast_path_equals_the_float64_expressions():
     reference's float64 atan2 / acos / sin decide otherwise.  (i) the approximations are within
     5e-7 of the float64 values (the margin assumes 1e-6); (ii) fast path + fallback and the float64
     expressions alone give the same colour for normals on and next to every checker edge."""
-    import subprocess
-
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostsim")])
-    hs = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     rng = np.random.default_rng(5)
     n = 2_000_000

@@ -368,6 +368,69 @@ def test_sharded_environment_equals_one_device(n, shards):
     many.close()
 
 
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_exact_mode_equals_one_device_through_auto_resets(shards):
+    """exact=True (rf_env_render_states / rf_env_step_end_given): the compacted row r of an auto-reset
+    is rendered by the shard owning environment slot r, as on one device (vector_environment.py:144 ->
+    state_observer.py:377-381 -> render.py:217) -- so 2 and 3 shards reproduce ONE
+    DeviceVectorDiscreteSteps bit for bit, observations, rewards, flags, environment states and RNG
+    states, through many auto-resets of few and of all environments."""
+    from reinfocus_amd.environments import harness
+
+    n, h = 13, 24
+    kw = dict(max_episode_steps=5, num_envs=n, frame_height=h, samples_per_pixel=3, seed=31)
+    one = harness.DeviceVectorDiscreteSteps(device=0, **kw)
+    many = harness.ShardedVectorDiscreteSteps(devices=[0] * shards, exact=True, **kw)
+    o1, _ = one.reset()
+    o2, _ = many.reset()
+    assert np.array_equal(o1, o2)
+    rng = np.random.default_rng(77)
+    steps_with_resets, sizes = 0, set()
+    for _ in range(28):
+        actions = rng.integers(0, 13, n)
+        a, b = one.step(actions), many.step(actions)
+        for x, y in zip(a[:4], b[:4]):
+            assert x.dtype == y.dtype and np.array_equal(x, y)
+        assert np.array_equal(one._state, many._state)
+        k = int(b[3].sum())
+        steps_with_resets += k > 0
+        sizes.add(k)
+    assert steps_with_resets >= 6 and len(sizes) >= 4  # partial sets of several sizes, and full ones
+    assert one._initializer._generator.bit_generator.state == many._initializer._generator.bit_generator.state
+    states = np.concatenate(many._each(lambda shard: shard.ctx.get_states()))
+    assert np.array_equal(states, one._ctx.get_states())
+    many.close()
+    one.close()
+
+
+def test_sharded_environment_renders_like_its_shards():
+    """render_mode="rgb_array" on the sharded environment: every shard draws what a single-context
+    environment over its range draws (600 px frames from its own renderer state + the plots), stacked
+    in shard order (vector_environment.py:166-176 -> episode_visualizer.py:188-201)."""
+    from reinfocus_amd.environments import harness
+
+    n, h = 3, 32
+    kw = dict(max_episode_steps=20, frame_height=h, samples_per_pixel=2)
+    many = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=[0, 0], render_mode="rgb_array", seed=2, **kw)
+    many.reset()
+    state0 = many._state
+    actions = np.array([5, 6, 7])
+    many.step(actions)
+    image = many.render()
+    assert image.dtype == np.uint8 and image.shape[0] == n * 600 and image.shape[1] > 600
+    many.close()
+    top = 0
+    for first, count in many._ranges:
+        single = harness.DeviceVectorDiscreteSteps(num_envs=count, render_mode="rgb_array", seed=0, device=0,
+                                                   first_state_index=first * h * h, **kw)
+        single.reset(state=state0[first:first + count])
+        single.step(actions[first:first + count])
+        part = single.render()
+        assert np.array_equal(image[top:top + count * 600], part)
+        top += count * 600
+        single.close()
+
+
 def test_two_phase_step_guards():
     """rf_env_step_begin / rf_env_step_end must alternate; rf_env_step refuses an open step."""
     from reinfocus_amd.environments import harness

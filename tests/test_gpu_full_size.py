@@ -187,3 +187,57 @@ def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, bra
         assert np.array_equal(host._renderer._ctx.get_states(first, h * h), dev._ctx.get_states(first, h * h))
     host.close()
     dev.close()
+
+
+@pytest.mark.parametrize("n,h,spp,shards", [(32768, 256, 16, 8), (1024, 512, 64, 8)])
+def test_whole_multi_gpu_configuration_on_eight_contexts(n, h, spp, shards):
+    """BASELINE configs[3] (32768 envs x 256 x 256 x 16 spp) and configs[4] (1024 envs x 512 x 512 x 64
+    spp) WHOLE, as the product object runs them on an 8-GPU node -- harness.ShardedVectorDiscreteSteps,
+    one context + one host thread per shard -- rehearsed with all eight contexts on this one device
+    (34 GB of RNG states: the 288 GB of one MI355X hold the node's whole workload).  Every shard's slice
+    must equal a single context seeded at that shard's first_state_index (global pixel index = e h w +
+    y w + x up to 2^31 - 1, graphics/render.py:217) and fed the rows of the ONE global initializer in
+    global index order (environments/vector_environment.py:138-142): reset, steps without ends, a step
+    in which the diverging rule ends a few environments of every shard, the step in which the time limit
+    ends the rest, and one more."""
+    import copy
+
+    from reinfocus_amd.environments import harness
+
+    kw = dict(max_episode_steps=4, frame_height=h, samples_per_pixel=spp)
+    many = harness.ShardedVectorDiscreteSteps(num_envs=n, devices=[0] * shards, seed=5, **kw)
+    assert many._ranges == [(g * (n // shards), n // shards) for g in range(shards)]
+    assert [s.first_state_index for s in many._shards] == [g * (n // shards) * h * h for g in range(shards)]
+    twin = harness._Initializer((5.0, 10.0), 5)  # the global initializer, replayed
+    obs0, _ = many.reset()
+    state0 = many._state
+    assert np.array_equal(state0, twin.initialize(n))
+    rng = np.random.default_rng(23)
+    record = []
+    for _ in range(5):
+        actions = rng.integers(0, 13, n)
+        pool = copy.deepcopy(twin._generator).uniform(5.0, 10.0, size=(n, 2)).astype(np.float32)
+        obs, rewards, _, truncated, _ = many.step(actions)
+        twin.initialize(int(truncated.sum())) if truncated.any() else None
+        record.append((actions, pool, obs, rewards, truncated, many._state))
+    ended = [int(r[4].sum()) for r in record]
+    assert ended[:2] == [0, 0] and 0 < ended[2] < n // 8 and ended[2] + ended[3] == n
+    assert twin._generator.bit_generator.state == many._initializer._generator.bit_generator.state
+    final_states = [shard.ctx.get_states(0, h * h) for shard in many._shards]
+    many.close()
+
+    for g, (first, count) in enumerate(many._ranges):
+        rows = slice(first, first + count)
+        single = harness.DeviceVectorDiscreteSteps(num_envs=count, seed=0, device=0, first_state_index=first * h * h, **kw)
+        o, _ = single.reset(state=state0[rows])
+        assert np.array_equal(o, obs0[rows]), f"shard {g}: reset"
+        for step, (actions, pool, obs, rewards, truncated, state) in enumerate(record):
+            r, t, k = single._ctx.env_step_begin(actions[rows])
+            before = int(truncated[:first].sum())  # environments that ended in the shards before this one
+            assert k == int(truncated[rows].sum())
+            got = single._ctx.env_step_end(pool[before:before + k])
+            assert np.array_equal(r, rewards[rows]) and np.array_equal(t, truncated[rows]), f"shard {g} step {step}"
+            assert np.array_equal(got, obs[rows]), f"shard {g} step {step}: observations"
+            assert np.array_equal(single._state, state[rows]), f"shard {g} step {step}: states"
+        assert np.array_equal(single._ctx.get_states(0, h * h), final_states[g])
+        single.close()

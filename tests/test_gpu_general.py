@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from tests import helpers
+
 from tests.test_general_renderer import _random_scene
 
 pytestmark = pytest.mark.gpu
@@ -91,13 +93,9 @@ def test_device_math_library_reaches_the_same_float32():
     in their last float64 bits; the checker sign identical to the reference's literal sin sign,
     including coordinates at and next to the checker's edges."""
     import ctypes
-    import subprocess
-
     here = os.path.dirname(os.path.abspath(__file__))
-    subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck"), "libgpucheck.so"])
-    subprocess.check_call(["make", "-C", os.path.join(here, "hostsim")])
-    gc = ctypes.CDLL(os.path.join(here, "gpucheck", "libgpucheck.so"))
-    hs = ctypes.CDLL(os.path.join(here, "hostsim", "libhostsim.so"))
+    gc = ctypes.CDLL(helpers.built("tests/gpucheck", "libgpucheck.so"))
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     n = 1_000_000
     count = ctypes.c_uint64(n)
@@ -136,15 +134,11 @@ def test_sphere_checker_fast_path_on_the_device():
     -- against the reference's float64 expressions evaluated on the host with glibc, for normals
     on and next to every checker edge."""
     import ctypes
-    import subprocess
-
     from tests.test_general_renderer import _normals_on_and_near_checker_edges
 
     here = os.path.dirname(os.path.abspath(__file__))
-    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "gpucheck"), "libgpucheck.so"])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "hostsim")])
-    gc = ctypes.CDLL(os.path.join(here, "gpucheck", "libgpucheck.so"))
-    hs = ctypes.CDLL(os.path.join(here, "hostsim", "libhostsim.so"))
+    gc = ctypes.CDLL(helpers.built("tests/gpucheck", "libgpucheck.so"))
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     n = 4_000_000
     normals, fu, fv = _normals_on_and_near_checker_edges(np.random.default_rng(9), n)

@@ -327,16 +327,24 @@ def test_fast_sqrt_and_reciprocal_are_ieee_exact(native):
     import ctypes
     import subprocess
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    so = os.path.join(here, "gpucheck", "libgpucheck.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck")])
-    lib = ctypes.CDLL(so)
+    lib = ctypes.CDLL(helpers.built("tests/gpucheck", "libgpucheck.so"))
     out = (ctypes.c_ulonglong * 3)()
     assert lib.gc_check_sqrt_rcp(out) == 0
     assert out[2] > 1_600_000_000          # values visited
     assert out[0] == 0, f"{out[0]} sqrt mismatches"
     assert out[1] == 0, f"{out[1]} reciprocal mismatches"
+
+
+def test_rejection_candidate_from_subnormal_bits_is_exact(native):
+    """approx_pm1 (rf_math.h) reads the top 23 bits of a draw as the bits of a SUBNORMAL float and
+    scales it with one fma: every one of the 2^32 high words must give k 2^-22 - 1 exactly on the
+    device (no flush-to-zero, no rounding) -- the band analysis of the rejection test rests on it."""
+    import ctypes
+
+    lib = ctypes.CDLL(helpers.built("tests/gpucheck", "libgpucheck.so"))
+    bad = ctypes.c_ulonglong(0)
+    assert lib.gc_check_approx_pm1(ctypes.byref(bad)) == 0
+    assert bad.value == 0, f"{bad.value} of 2^32 candidates differ"
 
 
 def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
@@ -372,10 +380,7 @@ def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path, h):
     must equal the oracle's, i.e. the production build's."""
     import subprocess
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    so = os.path.join(here, "gpucheck", "libreinfocus_cap32.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(here, "gpucheck"), "libreinfocus_cap32.so"])
+    so = helpers.built("tests/gpucheck", "libreinfocus_cap32.so")
     n, spp = 3, 8
     d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
     frames, final = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_HIP_LIB": so})

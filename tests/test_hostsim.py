@@ -21,8 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def hs():
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostsim")])
-    lib = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    lib = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     p = ctypes.c_void_p
     lib.hs_check_uniform.restype = ctypes.c_long
     lib.hs_check_uniform.argtypes = [p, ctypes.c_long]

@@ -28,6 +28,10 @@ class FakeContext:
         self.steps = np.zeros(n, dtype=np.int64)
         self.pending = None
         self.closed = False
+        self.first_env = first_env
+        self.rendered_rows = 0
+        self.aborted = False
+        self.fail_next_begin = False
 
     def _obs(self):
         return np.column_stack([self.state, self.steps, self.steps * 0]).astype(np.float32)
@@ -39,6 +43,9 @@ class FakeContext:
 
     def env_step_begin(self, actions):
         assert self.pending is None
+        if self.fail_next_begin:
+            self.fail_next_begin = False
+            raise RuntimeError("injected failure")
         self.state[:, 1] += np.asarray(actions, dtype=np.float32) * 0.125
         self.steps += 1
         truncated = self.steps >= self.period
@@ -52,6 +59,27 @@ class FakeContext:
         self.state[truncated] = rows
         self.steps[truncated] = 0
         return self._obs()
+
+    def env_render_states(self, states):
+        """Exact mode: "focus values" that say where a row was rendered (slot = first env + local row)."""
+        states = np.asarray(states, dtype=np.float32).reshape(-1, 2)
+        assert 0 < len(states) <= self.n
+        self.rendered_rows += len(states)
+        return (self.first_env + np.arange(len(states))) * 100.0 + states[:, 0].astype(np.float64)
+
+    def env_step_end_given(self, rows, focus):
+        truncated, self.pending = self.pending, None
+        rows = np.asarray(rows, dtype=np.float32).reshape(-1, 2)
+        assert len(rows) == truncated.sum() == len(focus)
+        self.state[truncated] = rows
+        self.steps[truncated] = 0
+        obs = self._obs()
+        obs[truncated, 3] = np.asarray(focus, dtype=np.float32)
+        return obs
+
+    def env_step_abort(self):
+        self.aborted = self.pending is not None
+        self.pending = None
 
     def env_states(self):
         return self.state.copy()
@@ -77,6 +105,12 @@ def fake_shards(monkeypatch):
             self.num_envs, self.device = num_envs, device
             self.ctx = FakeContext(num_envs, self.first_env)
             made.append(self)
+
+        def render(self, frame_height):  # what HistoryVisualizer asks of a renderer
+            return np.full((self.num_envs, frame_height, frame_height, 3), self.first_env, dtype=np.uint8)
+
+        def status(self, index):  # ... and of an ender
+            return f"env {self.first_env + index}"
 
     monkeypatch.setattr(harness, "_DeviceShard", FakeShard)
     monkeypatch.setattr(_native, "device_count", lambda: 4)
@@ -131,10 +165,91 @@ def test_sharded_defaults_and_guards(fake_shards):
     with pytest.raises(AssertionError):
         harness.ShardedVectorDiscreteSteps(num_envs=2, devices=[0, 1, 2], frame_height=8)
     with pytest.raises(AssertionError):
-        harness.ShardedVectorDiscreteSteps(num_envs=4, devices=[0], render_mode="rgb_array", frame_height=8)
+        harness.ShardedVectorDiscreteSteps(num_envs=4, devices=[0], render_mode="human", frame_height=8)
     # the env id reaches it through `devices`
     env = registration.make_vec("DiscreteSteps-v0", num_envs=6, devices=[0, 1], frame_height=8, samples_per_pixel=1)
     assert type(env) is harness.ShardedVectorDiscreteSteps and env.num_envs == 6
+    env.close()
+
+
+@pytest.mark.parametrize("n,devices", [(11, [0, 1, 2]), (9, [0, 1, 2, 3])])
+def test_exact_mode_renders_row_r_where_slot_r_lives(fake_shards, n, devices):
+    """exact=True: the compacted row r of an auto-reset is rendered by the shard that owns environment
+    slot r (its RNG states are the ones a single device would draw from, render.py:217) and the value
+    comes back to the shard the environment lives on -- so several shards equal one."""
+    from reinfocus_amd.environments import harness
+
+    kw = dict(num_envs=n, frame_height=16, samples_per_pixel=1, seed=9, exact=True)
+    many = harness.ShardedVectorDiscreteSteps(devices=devices, **kw)
+    mine = list(fake_shards)
+    one = harness.ShardedVectorDiscreteSteps(devices=[0], **kw)
+    assert np.array_equal(one.reset()[0], many.reset()[0])
+    rng = np.random.default_rng(2)
+    total = 0
+    for _ in range(10):
+        actions = rng.integers(0, 13, n)
+        a, b = one.step(actions), many.step(actions)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        k = int(b[3].sum())
+        if k:  # the "focus values" name the slots 0..k-1 in order, whichever environments ended
+            assert np.array_equal(b[0][b[3], 3] // 100, np.arange(k))
+        total += k
+    assert total > n
+    # the resets were rendered by the first shards only
+    rendered = [s.ctx.rendered_rows for s in sorted(mine, key=lambda s: s.first_env)]
+    assert sum(rendered) == total and rendered[0] > 0 and rendered[-1] == 0
+    many.close()
+    one.close()
+
+
+def test_a_failing_shard_does_not_leave_the_others_half_way(fake_shards):
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=9, devices=[0, 1, 2], frame_height=8, samples_per_pixel=1, seed=1)
+    env.reset()
+    shards = sorted(fake_shards, key=lambda s: s.first_env)
+    with pytest.raises(AssertionError):  # checked for all shards before any of them begins
+        env.step(np.array([0, 1, 2, 3, 4, 5, 6, 7, 13]))
+    assert all(s.ctx.pending is None and not s.ctx.aborted for s in shards)
+    shards[1].ctx.fail_next_begin = True
+    with pytest.raises(RuntimeError, match="injected failure"):
+        env.step(np.zeros(9, dtype=np.int64))
+    assert shards[0].ctx.aborted and shards[2].ctx.aborted and not shards[1].ctx.aborted
+    assert all(s.ctx.pending is None for s in shards)
+    env.reset()
+    env.step(np.zeros(9, dtype=np.int64))  # usable again after a reset
+    env.close()
+
+
+def test_every_shard_has_its_own_thread(fake_shards):
+    import threading
+
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=6, devices=[0, 1, 2], frame_height=8, samples_per_pixel=1)
+    seen = [set() for _ in range(3)]
+    for _ in range(5):
+        names = env._each(lambda shard: threading.current_thread().name)
+        for g, name in enumerate(names):
+            seen[g].add(name)
+    assert all(len(names) == 1 for names in seen) and len(set.union(*seen)) == 3
+    env.close()
+
+
+def test_sharded_render_mode_stacks_the_shards(fake_shards):
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=3, devices=[0, 1], render_mode="rgb_array", frame_height=8,
+                                             samples_per_pixel=1, seed=0)
+    env.reset()
+    env.step(np.array([1, 2, 3]))
+    frames = env.render_frames()
+    assert frames.shape == (3, 600, 600, 3) and list(frames[:, 0, 0, 0]) == [0, 0, 2]  # shard 0: envs 0-1, shard 1: env 2
+    image = env.render()
+    assert image.shape[0] == 3 * 600 and image.shape[1] > 600 and image.dtype == np.uint8
+    assert np.all(image[1200:, :600] == 2)  # the third row's rendering is shard 1's
+    assert env._visualizer._ender.status(2) == "env 2"
     env.close()
 
 
