@@ -141,9 +141,26 @@ RF_HD float unit_f32_int(uint64_t r)
 // two exact u32 conversions -- then a single f64->f32 RNE (the very cast numba performs)
 // and an exact power-of-two scaling.  Four instructions of the 4-cycle class, no rare path;
 // measured 2.6 % faster end to end than a two-f32 split with sticky bits (tools/ubench).
+#ifndef RF_CONV_MAGIC
+#define RF_CONV_MAGIC 0
+#endif
 RF_HD float unit_f32_scaled48(uint32_t r_hi, uint32_t r_lo)
 {
+#if RF_CONV_MAGIC
+    // The same exact 53-bit integer without the two u32 -> f64 conversions (slow-path instructions on
+    // gfx950, like the f64 fma): the bit patterns {0x45300000, hi} and {0x43300000, lo & ~0x7FF} ARE the
+    // doubles 2^84 + hi 2^32 and 2^52 + (lo & ~0x7FF); (A - (2^84 + 2^52)) is exact (a multiple of 2^32
+    // below 2^64), and adding B gives hi 2^32 + (lo & ~0x7FF) exactly (53 significant bits).  Two f64
+    // additions and the one rounding f64 -> f32.
+    const uint64_t a_bits = 0x4530000000000000ull | (uint64_t)r_hi;
+    const uint64_t b_bits = 0x4330000000000000ull | (uint64_t)(r_lo & 0xFFFFF800u);
+    double a, b;
+    __builtin_memcpy(&a, &a_bits, 8);
+    __builtin_memcpy(&b, &b_bits, 8);
+    const double d = (a - 19342813118337666422669312.0 /* 2^84 + 2^52 */) + b;
+#else
     const double d = __builtin_fma((double)r_hi, 4294967296.0, (double)(r_lo & 0xFFFFF800u));
+#endif
     return (float)d * 1.52587890625e-05f; // 2^-16
 }
 
