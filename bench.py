@@ -255,6 +255,18 @@ def committed_profile(kernel, frame, spp):
     return None, f"no committed PMC summary for {kernel} at frame {frame} / spp {spp}"
 
 
+def committed_static_mix(kernel):
+    """The static VALU mix by gfx950 issue class that profiles/summarize.py stored for this kernel instance
+    (newest round first), or None: what issue rate this instruction mix can reach."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        meta = json.load(open(path)).get("_meta", {})
+        if kernel_key((meta.get("config") or {}).get("kernel") or "") == kernel_key(kernel) and meta.get("static_valu_mix"):
+            return dict(meta["static_valu_mix"], file=os.path.basename(path), commit=meta.get("commit"))
+    return None
+
+
 def roofline_from_profile(profile, pixels_per_launch):
     e = profile["entry"]
     pixels = e["SQ_WAVES"] * float(e.get("pixels_per_wave", 64))
@@ -283,6 +295,16 @@ def roofline_from_profile(profile, pixels_per_launch):
                             "rocprofv3 --pmc child runs of this invocation"),
             "profile": {k: profile[k] for k in ("file", "commit", "config")},
         }
+        mix = committed_static_mix(profile["config"]["kernel"]) if profile.get("config") else None
+        if mix:
+            # 0.5 is reachable only by streams of fast-path instructions; this kernel's mix (static, by issue
+            # class, with the per-class costs of tools/ubench/pairbench) can reach between the first figure
+            # (nothing overlaps) and the second (the fast-path float operations hide behind slow-path ones)
+            low, high = mix["attainable_insts_per_cycle_per_simd"]
+            valu["attainable_for_this_mix"] = {"no_overlap": low, "fast_fp_hidden": high, "shares": mix["shares"],
+                                               "cycles_per_class": mix["cycles_per_class"],
+                                               "from_committed_profile": mix["file"], "commit": mix["commit"]}
+            valu["frac_of_attainable"] = [valu["achieved"] / high, valu["achieved"] / low]
     return traffic, valu
 
 

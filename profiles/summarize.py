@@ -34,15 +34,30 @@ def main(tag):
     shutil.copy(stats[-1], os.path.join(root, tag + "_kernel_stats.csv"))
     totals = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
-    for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    spans = collections.defaultdict(float)  # ns of the profiled launches, from the pass that holds GRBM_GUI_ACTIVE
+    for d in ("pmc_sq", "pmc_sq2", "pmc_mix", "pmc_mix2", "pmc_fetch", "pmc_write"):
         for f in sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
             seen = set()
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"].split("(")[0]
+                if r["Counter_Name"] == "SQ_INSTS_VALU" and d != "pmc_sq":
+                    totals[k]["SQ_INSTS_VALU@" + d] += float(r["Counter_Value"])  # the denominator of that pass
+                    continue
                 totals[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                if d == "pmc_sq" and r["Dispatch_Id"] not in seen:
+                if r["Dispatch_Id"] not in seen:
                     seen.add(r["Dispatch_Id"])
-                    launches[k] += 1
+                    if d == "pmc_sq":
+                        launches[k] += 1
+                    if d == "pmc_sq2" and "Start_Timestamp" in r:
+                        spans[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    # pixels the profiled process really rendered (bench.py prints rf_pixels_rendered per kernel)
+    pixels_by_kernel = {}
+    for log in ("pmc_sq.log",):
+        path = os.path.join(src, log)
+        if os.path.exists(path):
+            for line in open(path):
+                if line.startswith("{") and "render_pixels_by_kernel" in line:
+                    pixels_by_kernel = json.loads(line)["render_pixels_by_kernel"]
     out = {}
     for k, v in totals.items():
         if k.startswith("__amd"):
@@ -54,8 +69,23 @@ def main(tag):
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
         # pixels a wave of the render kernels owns (render_kernel_coop2: 3 pixel sets per thread)
-        if "render_kernel" in k:
+        key = k.replace("void ", "").replace("rf::", "").replace(" ", "")
+        if key in pixels_by_kernel and e.get("SQ_WAVES"):
+            e["pixels"] = float(pixels_by_kernel[key])
+            e["pixels_per_wave"] = e["pixels"] / e["SQ_WAVES"]
+            e["pixels_from"] = "rf_pixels_rendered of the profiled run"
+        elif "render_kernel" in k:
             e["pixels_per_wave"] = 192 if "render_kernel_coop2" in k else 64
+            e["pixels_from"] = "SQ_WAVES x pixels per wave (padded lanes included)"
+        # sustained shader clock under this kernel: GRBM_GUI_ACTIVE counts every XCD's busy cycles
+        if e.get("GRBM_GUI_ACTIVE") and spans.get(k):
+            e["sustained_clock_ghz"] = e["GRBM_GUI_ACTIVE"] / 8.0 / spans[k]
+        # dynamic instruction mix (counters of the pmc_mix passes, as shares of that pass's SQ_INSTS_VALU)
+        mix_total = e.get("SQ_INSTS_VALU@pmc_mix")
+        if mix_total:
+            e["valu_mix"] = {name[len("SQ_INSTS_VALU_"):].lower(): e[name] / mix_total
+                             for name in sorted(e) if name.startswith("SQ_INSTS_VALU_") and "@" not in name
+                             and name not in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64")}
         if "SQ_INSTS_VALU" in e and e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
         # SIMD cycles the kernel had per VALU instruction it issued (GRBM_GUI_ACTIVE counts every XCD's
@@ -86,11 +116,36 @@ def main(tag):
                 meta["config"] = {"envs": b["config"]["envs_per_gpu"], "frame": b["config"]["frame"],
                                   "spp": b["config"]["spp"], "kernel": b.get("roofline", {}).get("kernel")}
                 shutil.copy(bench_line, os.path.join(root, tag + "_bench.json"))
+    # static VALU mix of the profiled render kernel instance by gfx950 issue class (tools/isa_mix.py on the
+    # listing `make -C reinfocus_amd/csrc asm` writes), with the per-class costs measured by tools/ubench/pairbench
+    kernel = (meta["config"] or {}).get("kernel") or ""
+    match = __import__("re").match(r"render_kernel_coop2<(true|false), (\d+), (\d+), (\d+)>", kernel)
+    listing = os.path.join(root, "..", "reinfocus_amd", "csrc", "rf_abi.gfx950.s")
+    if match and os.path.exists(listing):
+        sys.path.insert(0, os.path.join(root, "..", "tools"))
+        import isa_mix
+
+        mangled = "_ZN2rf19render_kernel_coop2ILb%dELi%sELi%sELi%sEEEvNS_10RenderArgsE" % (
+            1 if match.group(1) == "true" else 0, match.group(2), match.group(3), match.group(4))
+        counts = isa_mix.mix(isa_mix.kernel_lines(listing, mangled))
+        total = float(sum(counts.values()))
+        if total:
+            shares = {c: n / total for c, n in counts.items()}
+            no_overlap = sum(shares[c] * isa_mix.COST[c] for c in shares)
+            fp_hidden = sum(shares[c] * isa_mix.COST[c] for c in shares if c != "fast-fp")
+            meta["static_valu_mix"] = {
+                "shares": shares, "cycles_per_class": isa_mix.COST,
+                "cycles_per_instruction_if_nothing_overlaps": no_overlap,
+                "cycles_per_instruction_if_fast_fp_is_hidden": fp_hidden,
+                "attainable_insts_per_cycle_per_simd": [1.0 / no_overlap, 1.0 / fp_hidden],
+                "source": "static mix of the kernel's ISA (tools/isa_mix.py); class costs: tools/ubench/pairbench, "
+                          "profiles/r03_pairbench_8w.txt",
+            }
     out["_meta"] = meta
     with open(os.path.join(root, tag + "_pmc.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(open(os.path.join(root, tag + "_kernel_stats.csv")).read())
-    print(json.dumps({k: {m: v[m] for m in v if m.startswith(("hbm", "valu", "launches", "wait", "inst_wait", "salu", "commit", "config"))}
+    print(json.dumps({k: {m: v[m] for m in v if m.startswith(("hbm", "valu", "launches", "wait", "inst_wait", "salu", "commit", "config", "sustained", "pixels"))}
                       for k, v in out.items()}, indent=1))
 
 

@@ -497,7 +497,8 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
 namespace {
 
 // enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
-int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, const float *rect, bool axis)
+int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, const float *rect, bool axis,
+                  bool count_pixels = true)
 {
     int rc = ensure_frames(ctx, n, h, w);
     if (rc != RF_OK)
@@ -594,7 +595,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         }
     }
     RF_HIP(hipGetLastError());
-    g_pixels_rendered += (unsigned long long)n * (unsigned long long)a.hw;
+    if (count_pixels) // (enqueue_env_step counts after the step: its launches may be replayed, and skip slots)
+        g_pixels_rendered += (unsigned long long)n * (unsigned long long)a.hw;
     if (ctx->ev_render.size() > 512)
         return drain_events(ctx->ev_render, ctx->render_ms, ctx->render_n);
     return RF_OK;
@@ -1006,7 +1008,7 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
     RF_HIP(hipMemcpyAsync(ctx->d_pool, pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const int *)ctx->d_actions);
-    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
     if (rc == RF_OK)
         rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
     if (rc != RF_OK)
@@ -1015,7 +1017,7 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
                        (const double *)ctx->d_var, 0);
     hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const float *)ctx->d_pool, rf::kEnvResetBoth);
-    rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
+    rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis, false);
     if (rc == RF_OK)
         rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
     if (rc != RF_OK)
@@ -1156,6 +1158,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                         return rc;
                     RF_HIP(hipGetLastError());
                     RF_HIP(hipStreamSynchronize(ctx->stream));
+                    g_pixels_rendered += (unsigned long long)(n + k) * (unsigned long long)h.frame_height * h.frame_height;
                     ctx->env_steps += 1;
                     ctx->env_scene_len = k > 0 ? k : n;
                     ctx->env_last_partial = k > 0;
@@ -1175,6 +1178,9 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             k = *(const int *)(st + o_cnt);
             ctx->env_last_branch = RF_ENV_BRANCH_GRAPH;
         }
+        // what this step really rendered: all n environments, then the k that ended (the other slots of the
+        // second launch exit at once)
+        g_pixels_rendered += (unsigned long long)(n + k) * (unsigned long long)h.frame_height * h.frame_height;
     } else {
         // the step's flags and rewards are final after the first half; the count sizes the partial render
         int rc = env_step_begin(ctx, host_actions, host_rewards, host_truncated, &k);

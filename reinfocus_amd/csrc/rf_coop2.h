@@ -77,6 +77,9 @@ static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in Coo
 #ifndef RF_COLOUR_LDS
 #define RF_COLOUR_LDS 2
 #endif
+#ifndef RF_GEOM_OPAQUE
+#define RF_GEOM_OPAQUE 1 // 0: let the compiler keep the per-thread geometry across the sample loop (it spills)
+#endif
 constexpr int kTileH2 = kTileH * kSets;
 
 // A 32-bit value nobody has to compute: the raw-draw words of a sample are written by the first
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 
     int sphere_trips = kCoopTrips2; // in-wave sphere attempts of the current sample (block-uniform)
     for (int k = 0; k < a.spp; ++k) {
-        const Geometry gk = geometry(Geometry::opaque(tid));
+        const Geometry gk = geometry(RF_GEOM_OPAQUE ? Geometry::opaque(tid) : tid);
         const PixelEnv &env = env0;
         uint32_t w[kSets][6];
         float s[kSets], t[kSets];

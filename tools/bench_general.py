@@ -1,25 +1,36 @@
 """Development benchmark of the general renderer (rf_render_general):
 the reference's notebook-style scenes (one rectangle / one sphere / two shapes per environment,
 per-environment cameras, 50-bounce find_colour), frames left on the device.
-usage (GPU box):  python tools/bench_general.py [n_envs] [frame] [spp]"""
+usage (GPU box):  python tools/bench_general.py [n_envs] [frame] [spp] [--scene one_rect|one_sphere|two_sphere|mixed]"""
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reinfocus_amd import _native  # noqa: E402
 from reinfocus_amd.graphics import camera, shape_factory as sf, world  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    frame = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    argv = list(sys.argv[1:])
+    only = None
+    if "--scene" in argv:  # one scene only (profiles/run_profiles.sh profiles them separately)
+        at = argv.index("--scene")
+        only = argv[at + 1]
+        del argv[at:at + 2]
+    n = int(argv[0]) if len(argv) > 0 else 256
+    frame = int(argv[1]) if len(argv) > 1 else 256
+    spp = int(argv[2]) if len(argv) > 2 else 16
     rng = np.random.default_rng(0)
     ctx = _native.Context(0)
     for label, make in (("one_rect", sf.one_rect), ("one_sphere", sf.one_sphere), ("two_sphere", None),
                         ("mixed", None)):
+        if only is not None and label != only:
+            rng.uniform(5, 10, 2 * n)  # keep the other scenes' parameters what they are in a full run
+            continue
         if make is not None:
             shapes = [make(sf.ShapeParameters(distance=float(d), r_size=20)) for d in rng.uniform(5, 10, n)]
         elif label == "two_sphere":

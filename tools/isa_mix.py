@@ -29,6 +29,29 @@ def classify(op):
     return "slow"
 
 
+def kernel_lines(asm_path, mangled):
+    """The lines of one kernel of a hipcc -S listing (label `mangled:` ... s_endpgm)."""
+    out, inside = [], False
+    for line in open(asm_path):
+        if line.startswith(mangled + ":"):
+            inside = True
+        if inside:
+            out.append(line.rstrip("\n"))
+            if "s_endpgm" in line:
+                break
+    return out
+
+
+def mix(lines):
+    """{class: count} of the VALU instructions in `lines`."""
+    counts = collections.Counter()
+    for line in lines:
+        m = re.match(r"\s+(v_[a-z0-9_]+)\b", line)
+        if m:
+            counts[classify(m.group(1))] += 1
+    return dict(counts)
+
+
 def main():
     lines = open(sys.argv[1]).read().splitlines()
     if len(sys.argv) > 3:
@@ -57,4 +80,5 @@ def main():
         print(f"  {c}: " + ", ".join(f"{op[2:]} {n}" for (cc, op), n in ops.most_common() if cc == c))
 
 
-main()
+if __name__ == "__main__":
+    main()
