@@ -258,13 +258,36 @@ RF_HD int checker_sign(float u, const CheckerTable &tab)
 
 // sin(32 pi u) * sin(32 pi v) > 0 for u, v >= 0: the common case (neither 32u nor 32v an
 // integer) is one parity test of trunc(32u) ^ trunc(32v); exact integers take the table.
+#ifndef RF_CHECKER_FP
+#define RF_CHECKER_FP 1
+#endif
 RF_HD bool checker_red(float u, float v, const CheckerTable &tab)
 {
     const float mu = u * 32.0f, mv = v * 32.0f;
+#if RF_CHECKER_FP
+    // The same parity without conversions and with one compare (float <-> int conversions and compares
+    // issue on gfx950's slow path, float adds and logic ops do not): for 0 <= m <= 32, a = m + 2^23 is
+    // m rounded to an integer r (ties to even) whose parity is the lowest bit of a's pattern; d = m - r
+    // is exact (|d| <= 1/2), negative exactly when r = floor(m) + 1 and zero exactly when m is an
+    // integer.  So parity(floor(m)) = (bits(a) ^ (bits(d) >> 31)) & 1; a zero product du * dv -- an
+    // integer point, or an underflow for coordinates no hit produces -- takes the table path, which is
+    // the literal logic and right for every input.
+    const float au = mu + 8388608.0f, av = mv + 8388608.0f;
+    const float du = mu - (au - 8388608.0f), dv = mv - (av - 8388608.0f);
+    if (__builtin_expect(du * dv == 0.0f, 0))
+        return (checker_sign(u, tab) * checker_sign(v, tab)) > 0;
+    uint32_t bau, bav, bdu, bdv;
+    __builtin_memcpy(&bau, &au, 4);
+    __builtin_memcpy(&bav, &av, 4);
+    __builtin_memcpy(&bdu, &du, 4);
+    __builtin_memcpy(&bdv, &dv, 4);
+    return (((bau ^ bav) ^ ((bdu ^ bdv) >> 31)) & 1u) == 0u;
+#else
     const int ku = (int)mu, kv = (int)mv; // trunc == floor: u, v >= 0
     if (__builtin_expect(mu == (float)ku || mv == (float)kv, 0))
         return (checker_sign(u, tab) * checker_sign(v, tab)) > 0;
     return ((ku ^ kv) & 1) == 0;
+#endif
 }
 
 // ---------------------------------------------------------------------------
