@@ -373,7 +373,10 @@ struct GeneralArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(kBlock, 5) void render_general_kernel(GeneralArgs a)
+#ifndef RF_GENERAL_OCC
+#define RF_GENERAL_OCC 5
+#endif
+__global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_kernel(GeneralArgs a)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4]; // the block's 256 pixels x 3 B, stored as 192 coalesced dwords
     const int e = blockIdx.y;
