@@ -77,6 +77,16 @@ static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in Coo
 #ifndef RF_COLOUR_LDS
 #define RF_COLOUR_LDS 2
 #endif
+#ifndef RF_MAYBE
+#define RF_MAYBE 0 // 1: rejection loops leave on "not certainly rejected" (one compare), exact test after the conversion
+#endif
+#if RF_MAYBE
+#define RF_DISC_TRY disc_attempt_maybe
+#define RF_SPHERE_TRY sphere_attempt_maybe
+#else
+#define RF_DISC_TRY disc_attempt
+#define RF_SPHERE_TRY sphere_attempt
+#endif
 #ifndef RF_GEOM_OPAQUE
 #define RF_GEOM_OPAQUE 1 // 0: let the compiler keep the per-thread geometry across the sample loop (it spills)
 #endif
@@ -132,10 +142,10 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
             state[slot[j]] = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
         if (need[j] && !parked[j]) { // overflow of the packed list: finish in place
             if (DIM == 2) {
-                while (!disc_attempt(g[j], w[j])) {
+                while (!RF_DISC_TRY(g[j], w[j])) {
                 }
             } else {
-                while (!sphere_attempt(g[j], w[j])) {
+                while (!RF_SPHERE_TRY(g[j], w[j])) {
                 }
             }
         }
@@ -160,7 +170,7 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
                 const uint4 ps = state[tid];
                 wg = Rng{ps.x, ps.y, ps.z, ps.w};
                 for (int trip = 0; trip < (DIM == 2 ? RF_R1_DISC : RF_R1_SPHERE); ++trip) {
-                    if (DIM == 2 ? disc_attempt(wg, ww) : sphere_attempt(wg, ww)) {
+                    if (DIM == 2 ? RF_DISC_TRY(wg, ww) : RF_SPHERE_TRY(wg, ww)) {
                         pend = false;
                         break;
                     }
@@ -194,10 +204,10 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
             Rng wg{ps.x, ps.y, ps.z, ps.w};
             uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
             if (DIM == 2) {
-                while (!disc_attempt(wg, ww)) {
+                while (!RF_DISC_TRY(wg, ww)) {
                 }
             } else {
-                while (!sphere_attempt(wg, ww)) {
+                while (!RF_SPHERE_TRY(wg, ww)) {
                 }
             }
             state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
@@ -216,10 +226,10 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
             Rng wg{ps.x, ps.y, ps.z, ps.w};
             uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
             if (DIM == 2) {
-                while (!disc_attempt(wg, ww)) {
+                while (!RF_DISC_TRY(wg, ww)) {
                 }
             } else {
-                while (!sphere_attempt(wg, ww)) {
+                while (!RF_SPHERE_TRY(wg, ww)) {
                 }
             }
             state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 #pragma unroll
             for (int trip = 0; trip < RF_COOP2_DISC_TRIPS; ++trip) {
                 if (trip == 0 || __any(need[j])) { // wave-uniform
-                    if (need[j] && disc_attempt(g[j], w[j]))
+                    if (need[j] && RF_DISC_TRY(g[j], w[j]))
                         need[j] = false;
                 }
             }
@@ -369,6 +379,18 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         for (int j = 0; j < kSets; ++j) {
             float p0, p1;
             disc_finish(w[j], p0, p1);
+#if RF_MAYBE
+            {
+                const bool redo = gk.live_of(j) && !disc_exact_ok(p0, p1); // inside the band, on the wrong side
+                if (__builtin_expect(__any(redo), 0)) {
+                    if (redo) {
+                        while (!disc_attempt(g[j], w[j])) {
+                        }
+                        disc_finish(w[j], p0, p1);
+                    }
+                }
+            }
+#endif
             pre[j] = sample_axis_ray<LENS>(p0, p1, env, a.cs, s[j], t[j], a.tab);
             w[j][4] = RF_WORD_INIT;
             w[j][5] = RF_WORD_INIT;
@@ -376,7 +398,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 #pragma unroll
             for (int trip = 0; trip < kCoopTrips2 + 1; ++trip) {
                 if ((trip < kCoopTrips2 || sphere_trips > kCoopTrips2) && __any(need[j])) { // wave-uniform
-                    if (need[j] && sphere_attempt(g[j], w[j]))
+                    if (need[j] && RF_SPHERE_TRY(g[j], w[j]))
                         need[j] = false;
                 }
             }
@@ -397,6 +419,18 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
             if (pre[j].hit)
                 sphere_finish(w[j], q0, q1, q2);
+#if RF_MAYBE
+            {
+                const bool redo = gk.live_of(j) && pre[j].hit && !sphere_exact_ok(q0, q1, q2);
+                if (__builtin_expect(__any(redo), 0)) {
+                    if (redo) {
+                        while (!sphere_attempt(g[j], w[j])) {
+                        }
+                        sphere_finish(w[j], q0, q1, q2);
+                    }
+                }
+            }
+#endif
             const Colour c = sample_axis_shade(pre[j], q0, q1, q2);
 #if RF_COLOUR_LDS > 0
             if (j < RF_COLOUR_LDS) {

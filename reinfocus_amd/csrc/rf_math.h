@@ -374,6 +374,26 @@ RF_HD bool disc_attempt(Rng &g, uint32_t w[4])
     return accept;
 }
 
+// "Not certainly rejected": one compare.  An attempt whose approximate squared length is >= 1 + band is
+// rejected by the reference too (the two lengths differ by less than the band); anything else leaves
+// the loop, and the caller settles it with the exact expression AFTER the exact conversion it performs
+// anyway (disc_exact_ok) -- if that says "rejected" (the candidate was inside the band and on the wrong
+// side: ~1e-5 of the attempts) the caller continues with disc_attempt.  Same decisions, one slow-path
+// compare and no band branch per attempt.
+RF_HD bool disc_attempt_maybe(Rng &g, uint32_t w[4])
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]);
+    return __builtin_fmaf(ta, ta, tb * tb) < 1.0f + kAcceptBand;
+}
+// camera.py:240: the reference's own test on the exactly converted candidate
+RF_HD bool disc_exact_ok(float p0, float p1)
+{
+    const float d0 = p0 * p0, d1 = p1 * p1;
+    return d0 + d1 < 1.0f;
+}
+
 RF_HD void disc_finish(const uint32_t w[4], float &p0, float &p1)
 {
     p0 = exact_pm1(w[0], w[1]);
@@ -403,6 +423,16 @@ RF_HD bool sphere_attempt(Rng &g, uint32_t w[6])
         accept = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5])) < 1.0f;
     return accept;
 }
+
+RF_HD bool sphere_attempt_maybe(Rng &g, uint32_t w[6]) // see disc_attempt_maybe
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    rng_next(g, w[4], w[5]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]), tc = approx_pm1(w[4]);
+    return __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc)) < 1.0f + kAcceptBand;
+}
+RF_HD bool sphere_exact_ok(float q0, float q1, float q2) { return sq_len(q0, q1, q2) < 1.0f; } // physics.py:31
 
 RF_HD void sphere_finish(const uint32_t w[6], float &q0, float &q1, float &q2)
 {
