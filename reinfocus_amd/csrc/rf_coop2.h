@@ -87,6 +87,16 @@ static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in Coo
 #define RF_DISC_TRY disc_attempt
 #define RF_SPHERE_TRY sphere_attempt
 #endif
+// TIMING EXPERIMENTS ONLY (wrong frames; never set in a shipped build): cap the trips of the sparse tail loops --
+// RF_TAILCAP_SPHERE: the second round of the sphere tails (one wave, ~6.5 trips), RF_TAILCAP_DISC: the disc
+// workers (three waves, ~3.5 trips).  What the kernel gains with a cap of 0 / 1 is the most any organisation
+// that removes / densifies those trips could gain.
+#if defined(RF_TAILCAP_SPHERE) || defined(RF_TAILCAP_DISC)
+#define RF_TAIL_LOOP(cap, attempt)                                                                 \
+    for (int trip_ = 0; trip_ < (cap); ++trip_)                                                    \
+        if (attempt)                                                                               \
+            break;
+#endif
 #ifndef RF_GEOM_OPAQUE
 #define RF_GEOM_OPAQUE 1 // 0: let the compiler keep the per-thread geometry across the sample loop (it spills)
 #endif
@@ -207,8 +217,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
                 while (!RF_DISC_TRY(wg, ww)) {
                 }
             } else {
+#ifdef RF_TAILCAP_SPHERE
+                RF_TAIL_LOOP(RF_TAILCAP_SPHERE, RF_SPHERE_TRY(wg, ww))
+#else
                 while (!RF_SPHERE_TRY(wg, ww)) {
                 }
+#endif
             }
             state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
             lds.words4[own] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
@@ -226,8 +240,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
             Rng wg{ps.x, ps.y, ps.z, ps.w};
             uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
             if (DIM == 2) {
+#ifdef RF_TAILCAP_DISC
+                RF_TAIL_LOOP(RF_TAILCAP_DISC, RF_DISC_TRY(wg, ww))
+#else
                 while (!RF_DISC_TRY(wg, ww)) {
                 }
+#endif
             } else {
                 while (!RF_SPHERE_TRY(wg, ww)) {
                 }

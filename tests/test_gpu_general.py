@@ -48,6 +48,26 @@ def test_general_random_scenes_match_oracle(ctx, oracle, n, h, w, spp, seed):
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
+def test_general_renderer_beyond_one_launch(ctx, oracle):
+    """rf_render_general in two chunks (65 535 environments per launch) with a frame whose byte size is
+    not a multiple of four (5 x 5 x 3 = 75): the second chunk's frames start at an address that is not
+    dword-aligned, so its blocks must take the byte-store path although their offsets within the chunk
+    look aligned.  Frames and final RNG states of all 65 540 environments against the oracle."""
+    n, h, w, spp = 65_540, 5, 5, 1
+    cameras8, (params8, types8, sizes8) = _random_scene(np.random.default_rng(8), 8)
+    reps = -(-n // 8)
+    cameras = np.ascontiguousarray(np.tile(cameras8, (reps, 1))[:n])
+    params = np.ascontiguousarray(np.tile(params8, (reps, 1, 1))[:n])
+    types = np.ascontiguousarray(np.tile(types8, (reps, 1))[:n])
+    sizes = np.ascontiguousarray(np.tile(sizes8, reps)[:n])
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+    got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+    assert np.array_equal(got[:65_535], want[:65_535]), "first chunk"
+    assert np.array_equal(got[65_535:], want[65_535:]), "second chunk"
+    assert np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
 def test_reference_render_tests():
     """tests/graphics/render_test.py:27-80 through reinfocus_amd.graphics.render.render."""
     from reinfocus_amd.graphics import camera, render, shape_factory as sf, world

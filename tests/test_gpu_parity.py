@@ -159,6 +159,26 @@ def test_lens_radius_forms(ctx, oracle, lens, h):
     assert np.array_equal(ctx.get_states(0, n * h * h), st)
 
 
+@pytest.mark.parametrize("h,w", [(8, 8), (6, 10)])
+def test_more_environments_than_one_launch_holds(ctx, oracle, h, w):
+    """A launch's grid holds 65 535 environments: larger batches are rendered and scored in chunks
+    (launch_render / launch_focus, rf_abi.hip).  65 600 environments -- frames, final RNG states and
+    focus values of every one of them, on both sides of the chunk boundary, against the oracle; the
+    6 x 10 frame takes the byte-store path (w % 4 != 0) with a chunk base that is not dword-aligned."""
+    n, spp = 65_600, 2
+    rng = np.random.Generator(np.random.PCG64DXSM(65))
+    d = helpers.pack_scene(*helpers.random_scene(rng, n))
+    states = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(d[0], d[1], h, w, spp, states, n_threads=16)
+    ctx.seed(n * h * w, 0, 0)
+    ctx.set_scene(*d)
+    got = ctx.render(n, h, w, spp, to_host=True)
+    assert np.array_equal(got[:65_535], want[:65_535]), "first chunk"
+    assert np.array_equal(got[65_535:], want[65_535:]), "second chunk"
+    assert np.array_equal(ctx.get_states(), states)
+    assert np.allclose(ctx.focus(n, h, w), oracle.focus_values(want, n_threads=16), rtol=1e-12, atol=0)
+
+
 def test_render_extreme_geometry(ctx, oracle):
     """Targets far outside [5, 10]: tiny/huge rectangles, strong defocus, t-range misses."""
     targets = np.array([1.0, 40.0, 0.0005, 2.0e6, 10.0, 5.0], dtype=np.float32)
