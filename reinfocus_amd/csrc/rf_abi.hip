@@ -70,6 +70,10 @@ struct rf_ctx {
     ulonglong2 *d_states = nullptr;
     uint64_t n_states = 0;
     ulonglong2 *d_mats = nullptr;
+    // rf_render_general re-creates seed-0 states for every call, as the reference does (render.py:115): a copy of
+    // the freshly seeded array turns all but the first seeding of a size into a device-to-device copy
+    ulonglong2 *d_seed_cache = nullptr;
+    uint64_t seed_cache_n = 0;
 
     float *d_cam = nullptr;
     float *d_rect = nullptr;
@@ -369,6 +373,7 @@ int rf_destroy(rf_ctx *ctx)
     }
     if (ctx->d_states) (void)hipFree(ctx->d_states);
     if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    if (ctx->d_seed_cache) (void)hipFree(ctx->d_seed_cache);
     if (ctx->d_cam) (void)hipFree(ctx->d_cam);
     if (ctx->d_rect) (void)hipFree(ctx->d_rect);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
@@ -776,6 +781,44 @@ int rf_timing_read(rf_ctx *ctx, double *render_ms, uint64_t *render_launches, do
 
 /* ---- general renderer ---------------------------------------------------------------------- */
 
+namespace {
+
+// make_random_states(n, seed 0) for rf_render_general: the jump-ahead seeding the first time a size is
+// asked for, a device-to-device copy of the remembered result afterwards (same bytes; sizes above
+// 4 GiB of states are seeded every time rather than remembered)
+int seed_zero_cached(rf_ctx *ctx, uint64_t n_states)
+{
+    constexpr uint64_t kMaxCachedStates = (4ull << 30) / sizeof(ulonglong2);
+    if (ctx->d_seed_cache && ctx->seed_cache_n == n_states && ctx->n_states == n_states) {
+        RF_HIP(hipSetDevice(ctx->device));
+        drop_env_graph(ctx);
+        RF_HIP(hipMemcpyAsync(ctx->d_states, ctx->d_seed_cache, n_states * sizeof(ulonglong2), hipMemcpyDeviceToDevice,
+                              ctx->stream));
+        return RF_OK;
+    }
+    int rc = rf_seed(ctx, n_states, 0, 0);
+    if (rc != RF_OK || n_states > kMaxCachedStates)
+        return rc;
+    if (ctx->seed_cache_n != n_states) {
+        RF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_seed_cache)
+            RF_HIP(hipFree(ctx->d_seed_cache));
+        ctx->d_seed_cache = nullptr;
+        ctx->seed_cache_n = 0;
+        if (hipMalloc((void **)&ctx->d_seed_cache, n_states * sizeof(ulonglong2)) != hipSuccess) {
+            (void)hipGetLastError(); // no room for the copy: keep seeding every time
+            ctx->d_seed_cache = nullptr;
+            return RF_OK;
+        }
+        ctx->seed_cache_n = n_states;
+    }
+    RF_HIP(hipMemcpyAsync(ctx->d_seed_cache, ctx->d_states, n_states * sizeof(ulonglong2), hipMemcpyDeviceToDevice,
+                          ctx->stream));
+    return RF_OK;
+}
+
+} // namespace
+
 int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *cameras, const float *params,
                       const int32_t *types, const int32_t *sizes, int most, int width, uint8_t *host_out)
 {
@@ -789,7 +832,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             RF_REQUIRE(types[(size_t)e * most + i] == 0 || types[(size_t)e * most + i] == 1,
                        "rf_render_general: unknown shape type");
     }
-    int rc = rf_seed(ctx, (uint64_t)n * h * w, 0, 0); // render.py:115: fresh seed-0 states per call
+    int rc = seed_zero_cached(ctx, (uint64_t)n * h * w); // render.py:115: fresh seed-0 states per call
     if (rc != RF_OK)
         return rc;
     rc = ensure_frames(ctx, n, h, w);

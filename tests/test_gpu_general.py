@@ -48,6 +48,28 @@ def test_general_random_scenes_match_oracle(ctx, oracle, n, h, w, spp, seed):
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
+def test_general_renderer_reseeds_for_every_call(ctx, oracle):
+    """render.render creates fresh seed-0 RNG states for every call (graphics/render.py:115).  The
+    context remembers the seeded array of the last size and copies it instead of seeding again: repeated
+    calls -- with other sizes, other seeds and a fast-path render in between -- must keep giving the
+    oracle's frames and final states."""
+    rng = np.random.default_rng(31)
+    n, h, w, spp = 5, 24, 40, 3
+    cameras, (params, types, sizes) = _random_scene(rng, n)
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=8)
+    for round_ in range(3):
+        got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+        assert np.array_equal(got, want), f"call {round_}"
+        assert np.array_equal(ctx.get_states(0, n * h * w), st)
+        if round_ == 0:  # another size: the remembered array is replaced ...
+            ctx.render_general(cameras[:2], params[:2], types[:2], sizes[:2], 16, 16, 1)
+        else:            # ... and here the states are re-seeded differently and advanced by the fast path
+            ctx.seed(n * h * w, 7, 3)
+            ctx.set_scene(*helpers.pack_scene(np.full(n, 7.0, dtype=np.float32), np.full(n, 6.0, dtype=np.float32)))
+            ctx.render(n, h, w, 2)
+
+
 def test_general_renderer_beyond_one_launch(ctx, oracle):
     """rf_render_general in two chunks (65 535 environments per launch) with a frame whose byte size is
     not a multiple of four (5 x 5 x 3 = 75): the second chunk's frames start at an address that is not
