@@ -35,6 +35,20 @@ def pytest_sessionstart(session):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, directory), target])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def shipped_libraries_match_their_sources():
+    """On the GPU box nothing is compiled: the product library (and the checkers) travelled with the
+    checkout.  If any of them is not the build of the sources next to it -- someone edited a header and did
+    not run __graft_entry__.build() before shipping -- the whole session fails here, loudly, instead of
+    testing something else."""
+    if os.path.exists("/dev/kfd"):
+        from tests import helpers
+
+        for library in ("reinfocus_amd/libreinfocus_hip.so", "oracle/librf_oracle.so"):
+            helpers.verify_srchash(os.path.join(ROOT, library))
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/), built on demand.  Test infrastructure only."""
