@@ -121,6 +121,12 @@ __device__ __forceinline__ uint32_t any_u32()
     return v;
 }
 
+// the 16-byte entry at byte offset `offset` of an LDS array of uint4
+__device__ __forceinline__ uint4 *entry16(uint4 *array, int offset)
+{
+    return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(array) + offset);
+}
+
 // coop_finish for kSets pixel sets at once.  The packed list holds kCoopCap entries (the LDS
 // arrays of CoopLds); stragglers that do not fit finish their loop in their own wave.  Returns
 // the number of stragglers the block had (block-uniform).
@@ -141,10 +147,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
     bool parked[kSets];
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
-        slot[j] = kCoopCap;
+        // (the counter counts in units of 16 bytes -- an entry of the state array -- so that what the atomic
+        // returns is the entry's byte offset, without a shift)
+        slot[j] = kCoopCap * 16;
         if (need[j])
-            slot[j] = atomicAdd(&lds.cnt[parity], 1);
-        parked[j] = need[j] && slot[j] < kCoopCap;
+            slot[j] = atomicAdd(&lds.cnt[parity], 16);
+        parked[j] = need[j] && slot[j] < kCoopCap * 16;
 #else
     unsigned long long ballot[kSets];
     int pop = 0;
@@ -167,9 +175,10 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ballot[j], 0));
         base += (int)__popcll(ballot[j]);
         parked[j] = need[j] && slot[j] < kCoopCap;
+        slot[j] *= 16; // byte offset of the entry, as in the atomic form
 #endif
         if (parked[j])
-            state[slot[j]] = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
+            *entry16(state, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
         if (need[j] && !parked[j]) { // overflow of the packed list: finish in place
             if (DIM == 2) {
                 while (!RF_DISC_TRY(g[j], w[j])) {
@@ -181,7 +190,11 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
         }
     }
     __syncthreads();
+#if RF_PARK_ATOMIC
+    const int stragglers = lds.cnt[parity] >> 4;
+#else
     const int stragglers = lds.cnt[parity];
+#endif
     const int total = min(stragglers, kCoopCap);
     if (total == 0) // block-uniform
         return 0;
@@ -212,6 +225,13 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
                         lds.words2[tid] = make_uint2(ww[4], ww[5]);
                 }
             }
+#if RF_PARK_ATOMIC
+            if (pend) { // as in the park step: one LDS atomic per surviving lane, in units of one entry's 16 bytes
+                const int off2 = atomicAdd(&lds.cnt2, 16);
+                *entry16(other, off2) = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds.owner) + (off2 >> 3)) = (uint16_t)tid;
+            }
+#else
             const unsigned long long b2 = __ballot(pend);
             if (b2 != 0) {
                 int base2 = 0;
@@ -225,9 +245,14 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
                     lds.owner[slot2] = (uint16_t)tid;
                 }
             }
+#endif
         }
         __syncthreads();
+#if RF_PARK_ATOMIC
+        const int total2 = lds.cnt2 >> 4;
+#else
         const int total2 = lds.cnt2;
+#endif
         if (tid < total2) {
             const uint4 ps = other[tid];
             const int own = lds.owner[tid];
@@ -282,12 +307,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
         if (parked[j]) {
-            const uint4 ps = state[slot[j]];
+            const uint4 ps = *entry16(state, slot[j]);
             g[j] = Rng{ps.x, ps.y, ps.z, ps.w};
-            const uint4 w4 = lds.words4[slot[j]];
+            const uint4 w4 = *entry16(lds.words4, slot[j]);
             w[j][0] = w4.x; w[j][1] = w4.y; w[j][2] = w4.z; w[j][3] = w4.w;
             if (DIM == 3) {
-                const uint2 w2 = lds.words2[slot[j]];
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lds.words2) + (slot[j] >> 1));
                 w[j][4] = w2.x; w[j][5] = w2.y;
             }
         }
