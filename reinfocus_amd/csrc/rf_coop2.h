@@ -366,12 +366,15 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         __device__ __forceinline__ int y_of(int j) const { return y0 + j * tTileH; }
         __device__ __forceinline__ bool live_of(int j) const { return live_x && y_of(j) < h; }
     };
+    static_assert((tWavesX & (tWavesX - 1)) == 0 && (tWaveW & (tWaveW - 1)) == 0, "masks and shifts below");
     auto geometry = [&](int t) {
-        const int wv = t >> 6, lane = t & 63;
-        const int wx = mirror ? (tWavesX - 1 - wv % tWavesX) : (wv % tWavesX);
+        // (unsigned masks and shifts: the signed / and % of the same powers of two cost sign fix-ups every iteration)
+        const unsigned ut = (unsigned)t, wv = ut >> 6, lane = ut & 63u;
+        const unsigned wq = wv & (unsigned)(tWavesX - 1);
+        const int wx = (int)(mirror ? (unsigned)(tWavesX - 1) - wq : wq);
         Geometry r;
-        r.col = wx * tWaveW + (lane % tWaveW);
-        r.row0 = (wv / tWavesX) * tWaveH + (lane / tWaveW);
+        r.col = wx * tWaveW + (int)(lane & (unsigned)(tWaveW - 1));
+        r.row0 = (int)(wv / (unsigned)tWavesX) * tWaveH + (int)(lane / (unsigned)tWaveW);
         r.x = tile_x * tTileW + r.col;
         r.y0 = tile_y * tTileH2 + r.row0;
         r.live_x = r.x < a.w;

@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r03_z; mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest (product = ugeom) rc=$? $(tail -1 $OUT/pytest.log)"
+REPS=3 bash tools/ab.sh tools/lib_base.so tools/lib_ugeom.so 2>&1 | tee $OUT/ab.log
+AB_ARGS="--envs-per-gpu 512 --frame 300 --spp 100" REPS=2 bash tools/ab.sh tools/lib_base.so tools/lib_ugeom.so 2>&1 | tee $OUT/ab300.log
