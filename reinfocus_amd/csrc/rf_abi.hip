@@ -887,8 +887,13 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             b.types = a.types + (size_t)e0 * most;
             b.sizes = a.sizes + e0;
             b.n = ne;
-            hipLaunchKernelGGL(rf::render_general_kernel, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
-            ctx->render_kernel = "render_general_kernel";
+            if (is_pow2(h) && is_pow2(w)) {
+                hipLaunchKernelGGL(rf::render_general_kernel<true>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
+                ctx->render_kernel = "render_general_kernel<true>";
+            } else {
+                hipLaunchKernelGGL(rf::render_general_kernel<false>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
+                ctx->render_kernel = "render_general_kernel<false>";
+            }
             he = hipGetLastError();
         }
     }

@@ -335,6 +335,9 @@ RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
 struct GeneralFrame {
     int h, w;
     bool quick;
+    // 1 / w, 1 / h for power-of-two frames: RN32(RN64(x + xi) / w) == RN32(x + xi) * 2^-k (rf_math.h
+    // pixel_coord_pow2), no float64 (the POW2 instance)
+    float inv_w, inv_h;
     double w64, h64, rw64, rh64;
 };
 
@@ -343,6 +346,8 @@ RF_HD GeneralFrame general_frame(int h, int w)
     GeneralFrame f;
     f.h = h;
     f.w = w;
+    f.inv_w = 1.0f / (float)w; // exact for the powers of two it is used for
+    f.inv_h = 1.0f / (float)h;
     f.quick = w <= 4096 && h <= 4096;
     f.w64 = (double)w;
     f.h64 = (double)h;
@@ -352,12 +357,17 @@ RF_HD GeneralFrame general_frame(int h, int w)
 }
 
 // render.py:61-66: the jittered coordinates of one sample, two draws (x first)
+// POW2: both frame sizes are powers of two (a separate kernel instance: the float64 coordinate code
+// is not even compiled into it)
+template <bool POW2>
 RF_HD void general_coords(Rng &g, int x, int y, const GeneralFrame &f, float &s, float &t)
 {
     const float xi = rng_uniform(g);
-    s = f.quick ? pixel_coord_div(x, xi, f.w64, f.rw64) : pixel_coord_literal(x, xi, f.w);
+    s = POW2 ? pixel_coord_pow2(x, xi, f.inv_w)
+             : (f.quick ? pixel_coord_div(x, xi, f.w64, f.rw64) : pixel_coord_literal(x, xi, f.w));
     const float yi = rng_uniform(g);
-    t = f.quick ? pixel_coord_div(y, yi, f.h64, f.rh64) : pixel_coord_literal(y, yi, f.h);
+    t = POW2 ? pixel_coord_pow2(y, yi, f.inv_h)
+             : (f.quick ? pixel_coord_div(y, yi, f.h64, f.rh64) : pixel_coord_literal(y, yi, f.h));
 }
 
 // camera.get_ray (camera.py:307-350) for a general camera frame; p is the lens-disc sample
@@ -374,6 +384,7 @@ RF_HD void general_ray(const CamDyn &dyn, const CamStatic &cs, float p0, float p
 }
 
 // one pixel of device_render
+template <bool POW2>
 RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, const GeneralCamera &cam,
                                 const float *params, const int32_t *types, int n_shapes, int width, float &cr,
                                 float &cg, float &cb)
@@ -385,7 +396,7 @@ RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, con
     const GeneralFrame frame = general_frame(h, w);
     for (int k = 0; k < spp; ++k) {
         float s, t;
-        general_coords(g, x, y, frame, s, t);
+        general_coords<POW2>(g, x, y, frame, s, t);
         float p0, p1;
         disc_sample(g, p0, p1);
         float o[3], d[3];

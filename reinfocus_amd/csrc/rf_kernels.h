@@ -376,6 +376,7 @@ struct GeneralArgs {
 #ifndef RF_GENERAL_OCC
 #define RF_GENERAL_OCC 5
 #endif
+template <bool POW2>
 __global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_kernel(GeneralArgs a)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4]; // the block's 256 pixels x 3 B, stored as 192 coalesced dwords
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_kernel(
         const ulonglong2 st = a.states[pix];
         Rng g = rng_load(st.x, st.y);
         float cr, cg, cb;
-        render_pixel_general(g, x, y, a.h, a.w, a.spp, a.cameras[e],
+        render_pixel_general<POW2>(g, x, y, a.h, a.w, a.spp, a.cameras[e],
                              a.params + ((size_t)e * a.most) * a.width, a.types + (size_t)e * a.most, a.sizes[e],
                              a.width, cr, cg, cb);
         a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));

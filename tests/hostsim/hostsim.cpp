@@ -68,14 +68,21 @@ int hs_render_general(uint8_t *frames, int n, int h, int w, int spp, const doubl
                       const int32_t *types, const int32_t *sizes, int most, int width, uint64_t *states)
 {
     const float scale = (float)(255.0 / (double)spp);
+    const bool pow2 = h > 0 && w > 0 && (h & (h - 1)) == 0 && (w & (w - 1)) == 0; // the instance rf_render_general launches
     for (int e = 0; e < n; ++e)
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
                 const long pix = ((long)e * h + y) * w + x;
                 Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
                 float cr, cg, cb;
-                render_pixel_general(g, x, y, h, w, spp, general_camera(cameras + (long)e * 19), params + ((long)e * most) * width,
-                                     types + (long)e * most, sizes[e], width, cr, cg, cb);
+                if (pow2)
+                    render_pixel_general<true>(g, x, y, h, w, spp, general_camera(cameras + (long)e * 19),
+                                               params + ((long)e * most) * width, types + (long)e * most, sizes[e], width, cr,
+                                               cg, cb);
+                else
+                    render_pixel_general<false>(g, x, y, h, w, spp, general_camera(cameras + (long)e * 19),
+                                                params + ((long)e * most) * width, types + (long)e * most, sizes[e], width, cr,
+                                                cg, cb);
                 states[2 * pix] = rng_s0(g);
                 states[2 * pix + 1] = rng_s1(g);
                 frames[pix * 3 + 0] = (uint8_t)(cr * scale);

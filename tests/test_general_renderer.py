@@ -175,8 +175,12 @@ def test_general_kernel_arithmetic_equals_oracle(oracle):
     hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     p = ctypes.c_void_p
     hs.hs_render_general.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p]
-    rng = np.random.default_rng(17)
-    n, h, w, spp = 6, 14, 20, 4
+    _general_kernel_case(oracle, hs, np.random.default_rng(17), 6, 14, 20, 4)
+    _general_kernel_case(oracle, hs, np.random.default_rng(18), 4, 16, 32, 5)  # powers of two: float32 coordinates
+    _general_kernel_case(oracle, hs, np.random.default_rng(19), 3, 8, 24, 3)   # one of each
+
+
+def _general_kernel_case(oracle, hs, rng, n, h, w, spp):
     cameras, (params, types, sizes) = _random_scene(rng, n)
     if params.shape[2] < 7:
         params = np.ascontiguousarray(np.pad(params, ((0, 0), (0, 0), (0, 7 - params.shape[2]))))
