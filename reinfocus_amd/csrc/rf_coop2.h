@@ -114,10 +114,29 @@ __device__ __forceinline__ uint32_t any_u32();
 #ifndef RF_WORD_INIT
 #define RF_WORD_INIT any_u32()
 #endif
+// Order of a draw's two raw words in an LDS entry: {low, high} is the order of the register pair the 64-bit sum
+// was written to, so that a 16-byte read can land where the words are used (no copies).
+#ifndef RF_WORDS_LOHI
+#define RF_WORDS_LOHI 1
+#endif
+#if RF_WORDS_LOHI
+#define RF_WORDS4(ww) make_uint4(ww[1], ww[0], ww[3], ww[2])
+#define RF_WORDS2(ww) make_uint2(ww[5], ww[4])
+#else
+#define RF_WORDS4(ww) make_uint4(ww[0], ww[1], ww[2], ww[3])
+#define RF_WORDS2(ww) make_uint2(ww[4], ww[5])
+#endif
+#ifndef RF_ANY_VOLATILE
+#define RF_ANY_VOLATILE 1
+#endif
 __device__ __forceinline__ uint32_t any_u32()
 {
     uint32_t v;
+#if RF_ANY_VOLATILE
+    asm volatile("" : "=v"(v)); // volatile: two calls are two values (merged, they cost a copy per use)
+#else
     asm("" : "=v"(v));
+#endif
     return v;
 }
 
@@ -125,6 +144,120 @@ __device__ __forceinline__ uint32_t any_u32()
 __device__ __forceinline__ uint4 *entry16(uint4 *array, int offset)
 {
     return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(array) + offset);
+}
+
+// The workers' part of a cooperative call: `total` parked entries (state[parity][0 .. total)) are finished by the
+// first lanes of the block; results in state / words4 / words2 at the entry's index.  Ends with a barrier.
+template <int DIM>
+__device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total, int tid)
+{
+    uint4 *const state = lds.state[parity];
+#if RF_TWO_ROUNDS
+    if (total > (DIM == 2 ? RF_TWO_ROUNDS_MIN_DISC : RF_TWO_ROUNDS_MIN)) { // block-uniform
+        // Round 1: the packed entries make a bounded number of attempts on as many waves as they
+        // fill; the survivors are packed again -- into the other parity's state buffer, idle
+        // during this call -- and finished in round 2 by (usually) a single wave, instead of every
+        // worker wave dragging its own sparse tail.
+        uint4 *const other = lds.state[parity ^ 1];
+        if (tid < ((total + 63) & ~63)) { // whole waves
+            bool pend = tid < total;
+            Rng wg{0, 0, 0, 0};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (pend) {
+                const uint4 ps = state[tid];
+                wg = Rng{ps.x, ps.y, ps.z, ps.w};
+                for (int trip = 0; trip < (DIM == 2 ? RF_R1_DISC : RF_R1_SPHERE); ++trip) {
+                    if (DIM == 2 ? RF_DISC_TRY(wg, ww) : RF_SPHERE_TRY(wg, ww)) {
+                        pend = false;
+                        break;
+                    }
+                }
+                if (!pend) {
+                    state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                    lds.words4[tid] = RF_WORDS4(ww);
+                    if (DIM == 3)
+                        lds.words2[tid] = RF_WORDS2(ww);
+                }
+            }
+#if RF_PARK_ATOMIC
+            if (pend) { // as in the park step: one LDS atomic per surviving lane, in units of one entry's 16 bytes
+                const int off2 = atomicAdd(&lds.cnt2, 16);
+                *entry16(other, off2) = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds.owner) + (off2 >> 3)) = (uint16_t)tid;
+            }
+#else
+            const unsigned long long b2 = __ballot(pend);
+            if (b2 != 0) {
+                int base2 = 0;
+                if ((tid & 63) == 0)
+                    base2 = atomicAdd(&lds.cnt2, (int)__popcll(b2));
+                base2 = __builtin_amdgcn_readfirstlane(base2);
+                const int slot2 = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+                if (pend) {
+                    other[slot2] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+                    lds.owner[slot2] = (uint16_t)tid;
+                }
+            }
+#endif
+        }
+        __syncthreads();
+#if RF_PARK_ATOMIC
+        const int total2 = lds.cnt2 >> 4;
+#else
+        const int total2 = lds.cnt2;
+#endif
+        if (tid < total2) {
+            const uint4 ps = other[tid];
+            const int own = lds.owner[tid];
+            Rng wg{ps.x, ps.y, ps.z, ps.w};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (DIM == 2) {
+                while (!RF_DISC_TRY(wg, ww)) {
+                }
+            } else {
+#ifdef RF_TAILCAP_SPHERE
+                RF_TAIL_LOOP(RF_TAILCAP_SPHERE, RF_SPHERE_TRY(wg, ww))
+#else
+                while (!RF_SPHERE_TRY(wg, ww)) {
+                }
+#endif
+            }
+            state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+            lds.words4[own] = RF_WORDS4(ww);
+            if (DIM == 3)
+                lds.words2[own] = RF_WORDS2(ww);
+        }
+        __syncthreads();
+        if (tid == 0)
+            lds.cnt2 = 0;
+    } else
+#endif
+    {
+        if (tid < total) {
+            const uint4 ps = state[tid];
+            Rng wg{ps.x, ps.y, ps.z, ps.w};
+            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+            if (DIM == 2) {
+#ifdef RF_TAILCAP_DISC
+                RF_TAIL_LOOP(RF_TAILCAP_DISC, RF_DISC_TRY(wg, ww))
+#else
+                while (!RF_DISC_TRY(wg, ww)) {
+                }
+#endif
+            } else {
+                while (!RF_SPHERE_TRY(wg, ww)) {
+                }
+            }
+            state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+            lds.words4[tid] = RF_WORDS4(ww);
+            if (DIM == 3)
+                lds.words2[tid] = RF_WORDS2(ww);
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        lds.cnt[parity] = 0;
 }
 
 // coop_finish for kSets pixel sets at once.  The packed list holds kCoopCap entries (the LDS
@@ -198,122 +331,96 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
     const int total = min(stragglers, kCoopCap);
     if (total == 0) // block-uniform
         return 0;
-#if RF_TWO_ROUNDS
-    if (total > (DIM == 2 ? RF_TWO_ROUNDS_MIN_DISC : RF_TWO_ROUNDS_MIN)) { // block-uniform
-        // Round 1: the packed entries make a bounded number of attempts on as many waves as they
-        // fill; the survivors are packed again -- into the other parity's state buffer, idle
-        // during this call -- and finished in round 2 by (usually) a single wave, instead of every
-        // worker wave dragging its own sparse tail.
-        uint4 *const other = lds.state[parity ^ 1];
-        if (tid < ((total + 63) & ~63)) { // whole waves
-            bool pend = tid < total;
-            Rng wg{0, 0, 0, 0};
-            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-            if (pend) {
-                const uint4 ps = state[tid];
-                wg = Rng{ps.x, ps.y, ps.z, ps.w};
-                for (int trip = 0; trip < (DIM == 2 ? RF_R1_DISC : RF_R1_SPHERE); ++trip) {
-                    if (DIM == 2 ? RF_DISC_TRY(wg, ww) : RF_SPHERE_TRY(wg, ww)) {
-                        pend = false;
-                        break;
-                    }
-                }
-                if (!pend) {
-                    state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-                    lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-                    if (DIM == 3)
-                        lds.words2[tid] = make_uint2(ww[4], ww[5]);
-                }
-            }
-#if RF_PARK_ATOMIC
-            if (pend) { // as in the park step: one LDS atomic per surviving lane, in units of one entry's 16 bytes
-                const int off2 = atomicAdd(&lds.cnt2, 16);
-                *entry16(other, off2) = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-                *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds.owner) + (off2 >> 3)) = (uint16_t)tid;
-            }
-#else
-            const unsigned long long b2 = __ballot(pend);
-            if (b2 != 0) {
-                int base2 = 0;
-                if ((tid & 63) == 0)
-                    base2 = atomicAdd(&lds.cnt2, (int)__popcll(b2));
-                base2 = __builtin_amdgcn_readfirstlane(base2);
-                const int slot2 = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
-                if (pend) {
-                    other[slot2] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-                    lds.owner[slot2] = (uint16_t)tid;
-                }
-            }
-#endif
-        }
-        __syncthreads();
-#if RF_PARK_ATOMIC
-        const int total2 = lds.cnt2 >> 4;
-#else
-        const int total2 = lds.cnt2;
-#endif
-        if (tid < total2) {
-            const uint4 ps = other[tid];
-            const int own = lds.owner[tid];
-            Rng wg{ps.x, ps.y, ps.z, ps.w};
-            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-            if (DIM == 2) {
-                while (!RF_DISC_TRY(wg, ww)) {
-                }
-            } else {
-#ifdef RF_TAILCAP_SPHERE
-                RF_TAIL_LOOP(RF_TAILCAP_SPHERE, RF_SPHERE_TRY(wg, ww))
-#else
-                while (!RF_SPHERE_TRY(wg, ww)) {
-                }
-#endif
-            }
-            state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-            lds.words4[own] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-            if (DIM == 3)
-                lds.words2[own] = make_uint2(ww[4], ww[5]);
-        }
-        __syncthreads();
-        if (tid == 0)
-            lds.cnt2 = 0;
-    } else
-#endif
-    {
-        if (tid < total) {
-            const uint4 ps = state[tid];
-            Rng wg{ps.x, ps.y, ps.z, ps.w};
-            uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-            if (DIM == 2) {
-#ifdef RF_TAILCAP_DISC
-                RF_TAIL_LOOP(RF_TAILCAP_DISC, RF_DISC_TRY(wg, ww))
-#else
-                while (!RF_DISC_TRY(wg, ww)) {
-                }
-#endif
-            } else {
-                while (!RF_SPHERE_TRY(wg, ww)) {
-                }
-            }
-            state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
-            lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
-            if (DIM == 3)
-                lds.words2[tid] = make_uint2(ww[4], ww[5]);
-        }
-        __syncthreads();
-    }
-    if (tid == 0)
-        lds.cnt[parity] = 0;
+    coop_workers<DIM>(lds, parity, total, tid);
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
         if (parked[j]) {
             const uint4 ps = *entry16(state, slot[j]);
             g[j] = Rng{ps.x, ps.y, ps.z, ps.w};
             const uint4 w4 = *entry16(lds.words4, slot[j]);
+#if RF_WORDS_LOHI
+            w[j][1] = w4.x; w[j][0] = w4.y; w[j][3] = w4.z; w[j][2] = w4.w;
+#else
             w[j][0] = w4.x; w[j][1] = w4.y; w[j][2] = w4.z; w[j][3] = w4.w;
+#endif
             if (DIM == 3) {
                 const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lds.words2) + (slot[j] >> 1));
+#if RF_WORDS_LOHI
+                w[j][5] = w2.x; w[j][4] = w2.y;
+#else
                 w[j][4] = w2.x; w[j][5] = w2.y;
+#endif
+            }
+        }
+    }
+    return stragglers;
+}
+
+// Lane predicates that live across the sample loop or a cooperative call are kept as 64-bit lane masks in scalar
+// registers (RF_MASKS): a `bool` that crosses control flow ends up as a 0 / 1 byte in a vector register -- one
+// v_cndmask to make it, a v_mov to clear it, a v_and + v_cmp to use it, all of them per set and phase, the compares on
+// the slow VALU path.  __builtin_amdgcn_inverse_ballot_w64 turns a mask back into the lanes' predicate without an
+// instruction (it is the s_and_saveexec operand).
+#ifndef RF_MASKS
+#define RF_MASKS 1
+#endif
+typedef unsigned long long lanemask;
+// a block-uniform integer condition, compared where it is used (s_cmp + s_cbranch_scc): hoisted out of the sample loop
+// as a boolean it becomes a lane mask that vector instructions test
+__device__ __forceinline__ int scalar_now(int v)
+{
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ lanemask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// coop_finish2 with the stragglers given as lane masks
+template <int DIM>
+__device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lanemask (&need)[kSets], Rng (&g)[kSets],
+                                             uint32_t (&w)[kSets][6], int tid)
+{
+    asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
+    uint4 *const state = lds.state[parity];
+    int slot[kSets];
+    lanemask parked[kSets];
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        // one LDS atomic per straggler, counting in units of an entry's 16 bytes (see coop_finish2)
+        slot[j] = (int)any_u32();
+        if (lane_in(need[j]))
+            slot[j] = atomicAdd(&lds.cnt[parity], 16);
+        parked[j] = need[j] & lanes_where(slot[j] < kCoopCap * 16); // (a ballot of one compare is that compare)
+        if (lane_in(parked[j]))
+            *entry16(state, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
+        if (lane_in(need[j] & ~parked[j])) { // overflow of the packed list: finish in place
+            if (DIM == 2) {
+                while (!RF_DISC_TRY(g[j], w[j])) {
+                }
+            } else {
+                while (!RF_SPHERE_TRY(g[j], w[j])) {
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int stragglers = lds.cnt[parity] >> 4;
+    const int total = min(stragglers, kCoopCap);
+    if (total == 0) // block-uniform
+        return 0;
+    coop_workers<DIM>(lds, parity, total, tid);
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        if (lane_in(parked[j])) {
+            const uint4 ps = *entry16(state, slot[j]);
+            g[j] = Rng{ps.x, ps.y, ps.z, ps.w};
+            const uint4 w4 = *entry16(lds.words4, slot[j]);
+            static_assert(RF_WORDS_LOHI, "entry layout");
+            w[j][1] = w4.x; w[j][0] = w4.y; w[j][3] = w4.z; w[j][2] = w4.w;
+            if (DIM == 3) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lds.words2) + (slot[j] >> 1));
+                w[j][5] = w2.x; w[j][4] = w2.y;
             }
         }
     }
@@ -338,6 +445,12 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
 
     const int e = blockIdx.y;
     const int tid = threadIdx.x;
+#ifdef RF_LDS_PAD // TIMING EXPERIMENTS ONLY: extra LDS per block, to take resident blocks away from a CU
+    __shared__ uint32_t lds_pad[RF_LDS_PAD / 4];
+    if (a.spp < 0)
+        lds_pad[tid] = (uint32_t)e;
+    asm volatile("" ::"v"(lds_pad[tid & 3]));
+#endif
     if (skip_env(a.rect, e)) // block-uniform, before any barrier
         return;
     if (tid < 2)
@@ -416,6 +529,96 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     }
 
     int sphere_trips = kCoopTrips2; // in-wave sphere attempts of the current sample (block-uniform)
+#if RF_MASKS
+    static_assert(RF_COOP2_DISC_TRIPS == 1 && !RF_MAYBE, "the mask form of the sample loop");
+    lanemask live_m[kSets]; // lanes whose pixel of set j is inside the frame
+#pragma unroll
+    for (int j = 0; j < kSets; ++j)
+        live_m[j] = lanes_where(geometry(tid).x < a.w) & lanes_where(geometry(tid).y_of(j) < a.h);
+    // per-environment conditions as scalars (a uniform `bool` is a lane mask that vector instructions test)
+    const int tmiss_s = __builtin_amdgcn_readfirstlane((int)env0.tmiss);
+    for (int k = 0; k < a.spp; ++k) {
+        const Geometry gk = geometry(RF_GEOM_OPAQUE ? Geometry::opaque(tid) : tid);
+        const PixelEnv &env = env0;
+        uint32_t w[kSets][6];
+        float s[kSets], t[kSets];
+        lanemask need_m[kSets];
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h64, a.w64, a.inv_w, a.inv_h,
+                                a.rw64, a.rh64, s[j], t[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                w[j][i] = RF_WORD_INIT;
+            // (every lane makes the attempt -- a wave's instructions cost the same with any lanes off, and a lane
+            // outside the frame never stores its state)
+            const float sq = disc_attempt_sq(g[j], w[j]);
+            need_m[j] = live_m[j] & ~lanes_where(sq < 1.0f);
+        }
+        coop_finish2m<2>(lds, 0, need_m, g, w, tid);
+
+        float rdx[kSets], rdy[kSets], rdz[kSets];
+        lanemask hit_m[kSets];
+        bool red[kSets];
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            float p0, p1;
+            disc_finish(w[j], p0, p1);
+            const AxisRay ray = sample_axis_point<LENS>(p0, p1, env, a.cs, s[j], t[j]);
+            rdx[j] = ray.dx;
+            rdy[j] = ray.dy;
+            rdz[j] = ray.dz;
+            // (the ballot of ONE compare is that compare; the lanes' predicate comes back from the mask)
+            hit_m[j] = live_m[j] & lanes_where(!(ray.reach > env.rect.half)); // rectangle.py:135
+            if (tmiss_s)                                          // rectangle.py:130
+                hit_m[j] = 0;
+            red[j] = false;
+            if (lane_in(hit_m[j]))
+                red[j] = sample_axis_red(ray.px, ray.py, env, a.tab);
+            w[j][4] = RF_WORD_INIT;
+            w[j][5] = RF_WORD_INIT;
+            need_m[j] = hit_m[j];
+#pragma unroll
+            for (int trip = 0; trip < kCoopTrips2 + 1; ++trip) {
+                if (trip >= kCoopTrips2 && scalar_now(sphere_trips) <= kCoopTrips2) // block-uniform, a scalar
+                    break;
+                if (need_m[j] != 0) { // wave-uniform
+                    float sq = 2.0f;
+                    if (lane_in(need_m[j]))
+                        sq = sphere_attempt_sq(g[j], w[j]);
+                    asm volatile("" : "+v"(sq)); // (or the compare moves into the branch and its ballot costs two more)
+                    need_m[j] &= ~lanes_where(sq < 1.0f);
+                }
+            }
+        }
+        // (the per-block switch between one and two in-wave attempts: see the bool form below)
+        const int stragglers = __builtin_amdgcn_readfirstlane(coop_finish2m<3>(lds, 1, need_m, g, w, tid));
+        if (sphere_trips == kCoopTrips2 && stragglers > kCoopCap + RF_ADAPT_ON)
+            sphere_trips = kCoopTrips2 + 1;
+        else if (sphere_trips != kCoopTrips2 && 2 * stragglers < kCoopCap + RF_ADAPT_OFF)
+            sphere_trips = kCoopTrips2;
+
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+            const bool hit = lane_in(hit_m[j]);
+            if (hit)
+                sphere_finish(w[j], q0, q1, q2);
+            const Colour c = sample_axis_shade(hit, red[j], rdx[j], rdy[j], rdz[j], q0, q1, q2);
+#if RF_COLOUR_LDS > 0
+            if (j < RF_COLOUR_LDS) {
+                lds_colour[j][0][tid] = add2_not_negzero(lds_colour[j][0][tid], c.r);
+                lds_colour[j][1][tid] = add2_not_negzero(lds_colour[j][1][tid], c.g);
+                lds_colour[j][2][tid] = add2_not_negzero(lds_colour[j][2][tid], c.b);
+                continue;
+            }
+#endif
+            cr[j] = add2_not_negzero(cr[j], c.r);
+            cg[j] = add2_not_negzero(cg[j], c.g);
+            cb[j] = add2_not_negzero(cb[j], c.b);
+        }
+    }
+#else
     for (int k = 0; k < a.spp; ++k) {
         const Geometry gk = geometry(RF_GEOM_OPAQUE ? Geometry::opaque(tid) : tid);
         const PixelEnv &env = env0;
@@ -512,6 +715,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             cb[j] = add2_not_negzero(cb[j], c.b);
         }
     }
+#endif // RF_MASKS
 #if RF_COLOUR_LDS > 0
 #pragma unroll
     for (int j = 0; j < RF_COLOUR_LDS && j < kSets; ++j) {

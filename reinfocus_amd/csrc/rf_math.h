@@ -136,7 +136,7 @@ RF_HD float unit_f32_int(uint64_t r)
     return ldexp_pow2((float)y, -32 - lz);
 }
 
-// Fast form: 2^48 * unit value as ONE correctly rounded f32 (callers fold the exact 2^-48
+// Fast form: 2^64 * unit value as ONE correctly rounded f32 (callers fold the exact 2^-64
 // into their next fma).  {hi, lo & ~0x7FF} is an exact 53-bit integer in f64 -- one fma of
 // two exact u32 conversions -- then a single f64->f32 RNE (the very cast numba performs)
 // and an exact power-of-two scaling.  Four instructions of the 4-cycle class, no rare path;
@@ -144,7 +144,7 @@ RF_HD float unit_f32_int(uint64_t r)
 #ifndef RF_CONV_MAGIC
 #define RF_CONV_MAGIC 1
 #endif
-RF_HD float unit_f32_scaled48(uint32_t r_hi, uint32_t r_lo)
+RF_HD float unit_f32_scaled64(uint32_t r_hi, uint32_t r_lo)
 {
 #if RF_CONV_MAGIC
     // The same exact 53-bit integer without the two u32 -> f64 conversions (slow-path instructions on
@@ -161,25 +161,25 @@ RF_HD float unit_f32_scaled48(uint32_t r_hi, uint32_t r_lo)
 #else
     const double d = __builtin_fma((double)r_hi, 4294967296.0, (double)(r_lo & 0xFFFFF800u));
 #endif
-    return (float)d * 1.52587890625e-05f; // 2^-16
+    return (float)d; // < 2^64: the scale is the consumer's (an exact power of two in its fma or product)
 }
 
-constexpr float kTwoM48 = 3.5527136788005009e-15f; // 2^-48
-constexpr float kTwoM47 = 7.1054273576010019e-15f; // 2^-47
+constexpr float kTwoM64 = 5.421010862427522e-20f;  // 2^-64
+constexpr float kTwoM63 = 1.0842021724855044e-19f; // 2^-63
 
-// 2^48 * xoroshiro128p_uniform_float32
-RF_HD float rng_uniform48(Rng &g)
+// 2^64 * xoroshiro128p_uniform_float32
+RF_HD float rng_uniform64(Rng &g)
 {
     uint32_t hi, lo;
     rng_next(g, hi, lo);
 #ifndef RF_UNIFORM_LITERAL
-    return unit_f32_scaled48(hi, lo);
+    return unit_f32_scaled64(hi, lo);
 #else
-    return ldexp_pow2(unit_f32_literal(((uint64_t)hi << 32) | lo), 48);
+    return ldexp_pow2(unit_f32_literal(((uint64_t)hi << 32) | lo), 64);
 #endif
 }
 
-RF_HD float rng_uniform(Rng &g) { return rng_uniform48(g) * kTwoM48; } // exact scaling
+RF_HD float rng_uniform(Rng &g) { return rng_uniform64(g) * kTwoM64; } // exact scaling
 
 // ---------------------------------------------------------------------------
 // scene parameters
@@ -354,7 +354,7 @@ RF_HD float approx_pm1(uint32_t r_hi) { return __builtin_fmaf((float)r_hi, kTwoM
 // == RN(xi*2f - 1f): the scalings by powers of two are exact
 RF_HD float exact_pm1(uint32_t r_hi, uint32_t r_lo)
 {
-    return __builtin_fmaf(unit_f32_scaled48(r_hi, r_lo), kTwoM47, -1.0f);
+    return __builtin_fmaf(unit_f32_scaled64(r_hi, r_lo), kTwoM63, -1.0f);
 }
 
 // One attempt of camera.py:229-252 random_in_unit_disc: two draws (raw words kept in
@@ -372,6 +372,23 @@ RF_HD bool disc_attempt(Rng &g, uint32_t w[4])
         accept = d0 + d1 < 1.0f;
     }
     return accept;
+}
+// The same attempt, returning a squared length whose comparison with 1 IS the reference's decision: the
+// approximate one outside the band (where it is on the same side of 1 as the reference's), the reference's own
+// inside.  For callers that want the decision as a lane mask after a join: `sq < 1` is then a single compare
+// (render_kernel_coop2, RF_MASKS).
+RF_HD float disc_attempt_sq(Rng &g, uint32_t w[4])
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]);
+    float sq = __builtin_fmaf(ta, ta, tb * tb);
+    if (__builtin_expect(__builtin_fabsf(sq - 1.0f) < kAcceptBand, 0)) {
+        const float e0 = exact_pm1(w[0], w[1]), e1 = exact_pm1(w[2], w[3]);
+        const float d0 = e0 * e0, d1 = e1 * e1;
+        sq = d0 + d1;
+    }
+    return sq;
 }
 
 // "Not certainly rejected": one compare.  An attempt whose approximate squared length is >= 1 + band is
@@ -422,6 +439,18 @@ RF_HD bool sphere_attempt(Rng &g, uint32_t w[6])
     if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0))
         accept = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5])) < 1.0f;
     return accept;
+}
+
+RF_HD float sphere_attempt_sq(Rng &g, uint32_t w[6]) // see disc_attempt_sq
+{
+    rng_next(g, w[0], w[1]);
+    rng_next(g, w[2], w[3]);
+    rng_next(g, w[4], w[5]);
+    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]), tc = approx_pm1(w[4]);
+    float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
+    if (__builtin_expect(__builtin_fabsf(sq - 1.0f) < kAcceptBand, 0))
+        sq = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5]));
+    return sq;
 }
 
 RF_HD bool sphere_attempt_maybe(Rng &g, uint32_t w[6]) // see disc_attempt_maybe
@@ -606,10 +635,10 @@ RF_HD float pixel_coord_pow2(int x, float xi, float inv_w)
 {
     return ((float)x + xi) * inv_w;
 }
-// same with xi48 = 2^48 * xi: fma(xi48, 2^-48, x) == RN(x + xi)
-RF_HD float pixel_coord_pow2_48(float xf, float xi48, float inv_w)
+// same with xi64 = 2^64 * xi: fma(xi64, 2^-64, x) == RN(x + xi)
+RF_HD float pixel_coord_pow2_64(float xf, float xi64, float inv_w)
 {
-    return __builtin_fmaf(xi48, kTwoM48, xf) * inv_w;
+    return __builtin_fmaf(xi64, kTwoM64, xf) * inv_w;
 }
 
 // ---------------------------------------------------------------------------
@@ -666,52 +695,76 @@ struct AxisPre {
     bool hit, red;
     float dx, dy, dz; // primary ray direction (the sky direction of a miss)
 };
+// the ray and where it meets the target's plane (rectangle.py:128-133), before the hit test
+struct AxisRay {
+    float dx, dy, dz;
+    float px, py;
+    float reach; // max(|p.x|, |p.y|): hit == !tmiss && !(reach > half)
+};
+
+template <int LENS = -1>
+RF_HD AxisRay sample_axis_point(float p0, float p1, const PixelEnv &e, const CamStatic &cs, float s, float t)
+{
+    float ox = lens_offset<LENS>(p0, cs);
+    float oy = lens_offset<LENS>(p1, cs);
+    AxisRay r;
+    r.dx = (e.dyn.llx + e.dyn.hx * s) - ox;
+    r.dy = (e.dyn.lly + e.dyn.vy * t) - oy;
+    r.dz = e.dyn.llz;
+    r.px = ox + r.dx * e.tt;
+    r.py = oy + r.dy * e.tt;
+    // rectangle.py:135: miss if p.x < -half or p.x > half or p.y < -half or p.y > half.
+    // == !(max(|p.x|, |p.y|) > half) including the NaN cases (maxNum drops a NaN operand,
+    // exactly as the four comparisons ignore it).
+    r.reach = __builtin_fmaxf(__builtin_fabsf(r.px), __builtin_fabsf(r.py));
+    return r;
+}
+
+// rectangle.uv + colour_checkerboard of a hit at (px, py): true = red
+RF_HD bool sample_axis_red(float px, float py, const PixelEnv &e, const CheckerTable &tab)
+{
+    const float half = e.rect.half;
+    float u, v;
+    if (e.fast_div) { // per-environment condition: uniform across the block
+        u = div_by_const(px + half, e.den, e.rden);
+        v = div_by_const(py + half, e.den, e.rden);
+    } else {
+        u = (px + half) / e.den;
+        v = (py + half) / e.den;
+    }
+    return checker_red(u, v, tab);
+}
 
 template <int LENS = -1>
 RF_HD AxisPre sample_axis_ray(float p0, float p1, const PixelEnv &e, const CamStatic &cs, float s, float t,
                               const CheckerTable &tab)
 {
-    float ox = lens_offset<LENS>(p0, cs);
-    float oy = lens_offset<LENS>(p1, cs);
+    const AxisRay ray = sample_axis_point<LENS>(p0, p1, e, cs, s, t);
     AxisPre r;
-    r.dx = (e.dyn.llx + e.dyn.hx * s) - ox;
-    r.dy = (e.dyn.lly + e.dyn.vy * t) - oy;
-    r.dz = e.dyn.llz;
-    float px = ox + r.dx * e.tt;
-    float py = oy + r.dy * e.tt;
-    const float half = e.rect.half;
-    // rectangle.py:135: miss if p.x < -half or p.x > half or p.y < -half or p.y > half.
-    // == !(max(|p.x|, |p.y|) > half) including the NaN cases (maxNum drops a NaN operand,
-    // exactly as the four comparisons ignore it).
-    r.hit = !e.tmiss && !(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)) > half);
+    r.dx = ray.dx;
+    r.dy = ray.dy;
+    r.dz = ray.dz;
+    r.hit = !e.tmiss && !(ray.reach > e.rect.half);
     r.red = false;
-    if (r.hit) {
-        float u, v;
-        if (e.fast_div) { // per-environment condition: uniform across the block
-            u = div_by_const(px + half, e.den, e.rden);
-            v = div_by_const(py + half, e.den, e.rden);
-        } else {
-            u = (px + half) / e.den;
-            v = (py + half) / e.den;
-        }
-        r.red = checker_red(u, v, tab);
-    }
+    if (r.hit)
+        r.red = sample_axis_red(ray.px, ray.py, e, tab);
     return r;
 }
 
 // physics.fast_find_colour's tail (physics.py:183-193) for a hit (scattered direction
 // N + q = (q0, q1, 1 + q2), attenuation red or green) or a miss (primary direction).
-RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
+// (hit / red given apart from the ray: render_kernel_coop2 keeps them as lane masks in scalar registers)
+RF_HD Colour sample_axis_shade(bool hit, bool red, float rdx, float rdy, float rdz, float q0, float q1, float q2)
 {
-    const float dx = r.hit ? q0 : r.dx, dy = r.hit ? q1 : r.dy, dz = r.hit ? 1.0f + q2 : r.dz;
+    const float dx = hit ? q0 : rdx, dy = hit ? q1 : rdy, dz = hit ? 1.0f + q2 : rdz;
     const float ud1 = unit_dir_y(dx, dy, dz);
     const float white = sky_white(ud1);
     Colour c;
-    if (r.hit) {
+    if (hit) {
         // attenuation (1,0,0) or (0,1,0): the other channels contribute +0
-        float ch = add2_not_negzero(white, sky_blue(ud1, r.red ? kSkyHalf[0] : kSkyHalf[1]));
-        c.r = r.red ? ch : 0.0f;
-        c.g = r.red ? 0.0f : ch;
+        float ch = add2_not_negzero(white, sky_blue(ud1, red ? kSkyHalf[0] : kSkyHalf[1]));
+        c.r = red ? ch : 0.0f;
+        c.g = red ? 0.0f : ch;
         c.b = 0.0f;
     } else {
         c.r = add2_not_negzero(white, sky_blue(ud1, kSkyHalf[0]));
@@ -719,6 +772,10 @@ RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
         c.b = add2_not_negzero(white, sky_blue(ud1, kSkyHalf[2]));
     }
     return c;
+}
+RF_HD Colour sample_axis_shade(const AxisPre &r, float q0, float q1, float q2)
+{
+    return sample_axis_shade(r.hit, r.red, r.dx, r.dy, r.dz, q0, q1, q2);
 }
 
 RF_HD AxisPre sample_axis_pre(Rng &g, const PixelEnv &e, const CamStatic &cs, float s, float t,
@@ -747,9 +804,9 @@ RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, double h64, d
     uint32_t xh, xl, yh, yl;
     rng_next(g, xh, xl);
     rng_next(g, yh, yl);
-    const float xi = unit_f32_scaled48(xh, xl), yi = unit_f32_scaled48(yh, yl); // 2^48 * uniform
-    s = POW2 ? pixel_coord_pow2_48(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM48, w64, rw64);
-    t = POW2 ? pixel_coord_pow2_48(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM48, h64, rh64);
+    const float xi = unit_f32_scaled64(xh, xl), yi = unit_f32_scaled64(yh, yl); // 2^64 * uniform
+    s = POW2 ? pixel_coord_pow2_64(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM64, w64, rw64);
+    t = POW2 ? pixel_coord_pow2_64(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM64, h64, rh64);
 }
 
 template <bool AXIS, bool POW2>

@@ -99,7 +99,7 @@ long hs_check_uniform(const uint64_t *words, long n)
     for (long i = 0; i < n; ++i) {
         float a = unit_f32_int(words[i]);
         float b = unit_f32_literal(words[i]);
-        float c = unit_f32_scaled48((uint32_t)(words[i] >> 32), (uint32_t)words[i]) * kTwoM48;
+        float c = unit_f32_scaled64((uint32_t)(words[i] >> 32), (uint32_t)words[i]) * kTwoM64;
         if (!(a == b) || !(c == b))
             ++bad;
     }
@@ -219,6 +219,24 @@ long hs_check_accept(const uint64_t *words, long n, int dims, long *in_band)
                 e[k] = exact_pm1((uint32_t)(words[i * dims + k] >> 32), (uint32_t)words[i * dims + k]);
             const bool exact = dims == 2 ? disc_exact_ok(e[0], e[1]) : sphere_exact_ok(e[0], e[1], e[2]);
             if ((maybe && exact) != want || (want && !maybe))
+                ++bad;
+        }
+        // the squared-length form (disc_attempt_sq / sphere_attempt_sq): the approximate length outside the band,
+        // the reference's own inside; its comparison with 1 must be the reference's decision
+        {
+            float sq2 = sq;
+            if (__builtin_fabsf(sq2 - 1.0f) < kAcceptBand) {
+                float e[3] = {0, 0, 0};
+                for (int k = 0; k < dims; ++k)
+                    e[k] = exact_pm1((uint32_t)(words[i * dims + k] >> 32), (uint32_t)words[i * dims + k]);
+                if (dims == 2) {
+                    const float d0 = e[0] * e[0], d1 = e[1] * e[1];
+                    sq2 = d0 + d1;
+                } else {
+                    sq2 = sq_len(e[0], e[1], e[2]);
+                }
+            }
+            if ((sq2 < 1.0f) != want)
                 ++bad;
         }
     }
