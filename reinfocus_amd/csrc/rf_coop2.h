@@ -203,7 +203,7 @@ __device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total
         }
         __syncthreads();
 #if RF_PARK_ATOMIC
-        const int total2 = lds.cnt2 >> 4;
+        const int total2 = __builtin_amdgcn_readfirstlane(lds.cnt2) >> 4;
 #else
         const int total2 = lds.cnt2;
 #endif
@@ -387,10 +387,14 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
     lanemask parked[kSets];
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
-        // one LDS atomic per straggler, counting in units of an entry's 16 bytes (see coop_finish2)
+        // one LDS atomic per straggler, counting in units of an entry's 16 bytes (see coop_finish2); all sets'
+        // atomics are issued before the first result is waited for
         slot[j] = (int)any_u32();
         if (lane_in(need[j]))
             slot[j] = atomicAdd(&lds.cnt[parity], 16);
+    }
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
         parked[j] = need[j] & lanes_where(slot[j] < kCoopCap * 16); // (a ballot of one compare is that compare)
         if (lane_in(parked[j]))
             *entry16(state, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
@@ -405,7 +409,7 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
         }
     }
     __syncthreads();
-    const int stragglers = lds.cnt[parity] >> 4;
+    const int stragglers = __builtin_amdgcn_readfirstlane(lds.cnt[parity]) >> 4; // (a scalar: the branches below are s_cmp)
     const int total = min(stragglers, kCoopCap);
     if (total == 0) // block-uniform
         return 0;
@@ -480,11 +484,14 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         __device__ __forceinline__ bool live_of(int j) const { return live_x && y_of(j) < h; }
     };
     static_assert((tWavesX & (tWavesX - 1)) == 0 && (tWaveW & (tWaveW - 1)) == 0, "masks and shifts below");
+    const unsigned mirror_mask = mirror ? (unsigned)(tWavesX - 1) : 0u;
     auto geometry = [&](int t) {
         // (unsigned masks and shifts: the signed / and % of the same powers of two cost sign fix-ups every iteration)
+        __builtin_assume(t >= 0 && t < kBlock); // (the per-iteration index is opaque: without this, bits 8.. are computed with)
         const unsigned ut = (unsigned)t, wv = ut >> 6, lane = ut & 63u;
         const unsigned wq = wv & (unsigned)(tWavesX - 1);
-        const int wx = (int)(mirror ? (unsigned)(tWavesX - 1) - wq : wq);
+        // mirrored blocks count their waves from the right: (tWavesX - 1) - wq == wq ^ (tWavesX - 1), a block-uniform mask
+        const int wx = (int)(wq ^ mirror_mask);
         Geometry r;
         r.col = wx * tWaveW + (int)(lane & (unsigned)(tWaveW - 1));
         r.row0 = (int)(wv / (unsigned)tWavesX) * tWaveH + (int)(lane / (unsigned)tWaveW);
@@ -538,15 +545,16 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     // per-environment conditions as scalars (a uniform `bool` is a lane mask that vector instructions test)
     const int tmiss_s = __builtin_amdgcn_readfirstlane((int)env0.tmiss);
     for (int k = 0; k < a.spp; ++k) {
-        const Geometry gk = geometry(RF_GEOM_OPAQUE ? Geometry::opaque(tid) : tid);
         const PixelEnv &env = env0;
         uint32_t w[kSets][6];
         float s[kSets], t[kSets];
         lanemask need_m[kSets];
+        const Geometry gk = geometry(RF_GEOM_OPAQUE ? Geometry::opaque(tid) : tid);
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
-            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y_of(j), a.h64, a.w64, a.inv_w, a.inv_h,
-                                a.rw64, a.rh64, s[j], t[j]);
+            // ((float)y of the further sets by an exact float addition: conversions issue on the slow path)
+            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y0 + (float)(j * tTileH), a.h64, a.w64,
+                                a.inv_w, a.inv_h, a.rw64, a.rh64, s[j], t[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 w[j][i] = RF_WORD_INIT;
