@@ -148,10 +148,19 @@ __device__ __forceinline__ uint4 *entry16(uint4 *array, int offset)
 
 // The workers' part of a cooperative call: `total` parked entries (state[parity][0 .. total)) are finished by the
 // first lanes of the block; results in state / words4 / words2 at the entry's index.  Ends with a barrier.
+#ifndef RF_TAIL_PRIO
+#define RF_TAIL_PRIO 1 // s_setprio of the waves inside coop_workers: the tails are the block's critical path (0 / 1 / 2 / 3: 151.5 / 155.5 / 154.8 / 153.7 k env-steps/s)
+#endif
+#ifndef RF_TAIL_PRIO_R2_ONLY
+#define RF_TAIL_PRIO_R2_ONLY 0
+#endif
 template <int DIM>
 __device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total, int tid)
 {
     uint4 *const state = lds.state[parity];
+#if RF_TAIL_PRIO && !RF_TAIL_PRIO_R2_ONLY
+    __builtin_amdgcn_s_setprio(RF_TAIL_PRIO);
+#endif
 #if RF_TWO_ROUNDS
     if (total > (DIM == 2 ? RF_TWO_ROUNDS_MIN_DISC : RF_TWO_ROUNDS_MIN)) { // block-uniform
         // Round 1: the packed entries make a bounded number of attempts on as many waves as they
@@ -207,6 +216,9 @@ __device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total
 #else
         const int total2 = lds.cnt2;
 #endif
+#if RF_TAIL_PRIO && RF_TAIL_PRIO_R2_ONLY
+        __builtin_amdgcn_s_setprio(RF_TAIL_PRIO);
+#endif
         if (tid < total2) {
             const uint4 ps = other[tid];
             const int own = lds.owner[tid];
@@ -256,6 +268,9 @@ __device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total
         }
         __syncthreads();
     }
+#if RF_TAIL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (tid == 0)
         lds.cnt[parity] = 0;
 }
