@@ -379,6 +379,12 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
 #ifndef RF_MASKS
 #define RF_MASKS 1
 #endif
+#ifndef RF_COLOUR_ATOMIC
+// 1: the colour sums in LDS by ds_add_f32 instead of read + add + write.  Bit-identical (tests/gpucheck
+// gc_check_lds_add) and 2.5x slower end to end (61.8 k against 155.4 k env-steps/s): the LDS unit's float atomics
+// are nowhere near one wave instruction per few cycles.
+#define RF_COLOUR_ATOMIC 0
+#endif
 typedef unsigned long long lanemask;
 // a block-uniform integer condition, compared where it is used (s_cmp + s_cbranch_scc): hoisted out of the sample loop
 // as a boolean it becomes a lane mask that vector instructions test
@@ -630,9 +636,16 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             const Colour c = sample_axis_shade(hit, red[j], rdx[j], rdy[j], rdz[j], q0, q1, q2);
 #if RF_COLOUR_LDS > 0
             if (j < RF_COLOUR_LDS) {
+#if RF_COLOUR_ATOMIC
+                // ds_add_f32: the LDS unit's float32 addition, nothing returned, nothing to wait for (measured: see above)
+                atomicAdd(&lds_colour[j][0][tid], c.r);
+                atomicAdd(&lds_colour[j][1][tid], c.g);
+                atomicAdd(&lds_colour[j][2][tid], c.b);
+#else
                 lds_colour[j][0][tid] = add2_not_negzero(lds_colour[j][0][tid], c.r);
                 lds_colour[j][1][tid] = add2_not_negzero(lds_colour[j][1][tid], c.g);
                 lds_colour[j][2][tid] = add2_not_negzero(lds_colour[j][2][tid], c.b);
+#endif
                 continue;
             }
 #endif

@@ -1,0 +1,8 @@
+#!/bin/bash
+# colour sums by ds_add_f32 (no read-modify-write, nothing to wait for)
+set -u
+OUT=gpurun_out/r03_catom; mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc $(tail -1 $OUT/pytest.log)"
+[ $rc -eq 0 ] || { tail -30 $OUT/pytest.log; exit $rc; }
+REPS=3 bash tools/ab.sh tools/lib_base.so tools/lib_catom.so 2>&1 | tee $OUT/ab.log
+AB_ARGS="--envs-per-gpu 512 --frame 300 --spp 100" REPS=2 bash tools/ab.sh tools/lib_base.so tools/lib_catom.so 2>&1 | tee $OUT/ab300.log
