@@ -379,6 +379,9 @@ __device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&nee
 #ifndef RF_MASKS
 #define RF_MASKS 1
 #endif
+#ifndef RF_PARK_WAVE
+#define RF_PARK_WAVE -1 // list slots per wave (1) / per straggler (0) / per kernel instance (-1): see coop_finish2m
+#endif
 #ifndef RF_COLOUR_ATOMIC
 // 1: the colour sums in LDS by ds_add_f32 instead of read + add + write.  Bit-identical (tests/gpucheck
 // gc_check_lds_add) and 2.5x slower end to end (61.8 k against 155.4 k env-steps/s): the LDS unit's float atomics
@@ -398,7 +401,12 @@ __device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_in
 __device__ __forceinline__ lanemask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // coop_finish2 with the stragglers given as lane masks
-template <int DIM>
+// WAVE_SLOTS: the stragglers' list slots by ONE LDS atomic per wave and call -- the masks are the ballots, the ranks
+// come from v_mbcnt (3 vector instructions per set) -- instead of one LDS atomic per straggler (no vector instruction;
+// the LDS unit serialises the lanes of a same-address atomic, and it is 40 % busy in this kernel).  Measured per kernel
+// instance (profiles/r03_ab.txt): power-of-two frames +1.0 ... +1.7 % (128 / 256 / 512 px), the others, whose float64
+// pixel coordinates leave them more issue-bound, -1.3 ... -2.3 % (300 / 384 / 600 px): the kernel takes it for POW2.
+template <int DIM, bool WAVE_SLOTS>
 __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lanemask (&need)[kSets], Rng (&g)[kSets],
                                              uint32_t (&w)[kSets][6], int tid)
 {
@@ -406,13 +414,35 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
     uint4 *const state = lds.state[parity];
     int slot[kSets];
     lanemask parked[kSets];
+    if (RF_PARK_WAVE < 0 ? WAVE_SLOTS : RF_PARK_WAVE != 0) {
+        int pop[kSets], all = 0;
 #pragma unroll
-    for (int j = 0; j < kSets; ++j) {
-        // one LDS atomic per straggler, counting in units of an entry's 16 bytes (see coop_finish2); all sets'
-        // atomics are issued before the first result is waited for
-        slot[j] = (int)any_u32();
-        if (lane_in(need[j]))
-            slot[j] = atomicAdd(&lds.cnt[parity], 16);
+        for (int j = 0; j < kSets; ++j) {
+            pop[j] = (int)__builtin_popcountll(need[j]);
+            all += pop[j];
+        }
+        int base = 0;
+        if (all != 0) { // wave-uniform
+            if ((tid & 63) == 0)
+                base = atomicAdd(&lds.cnt[parity], all * 16);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need[j] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)need[j], 0));
+            slot[j] = base + rank * 16;
+            base += pop[j] * 16;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSets; ++j) {
+            // one LDS atomic per straggler, counting in units of an entry's 16 bytes (see coop_finish2); all sets'
+            // atomics are issued before the first result is waited for
+            slot[j] = (int)any_u32();
+            if (lane_in(need[j]))
+                slot[j] = atomicAdd(&lds.cnt[parity], 16);
+        }
     }
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
@@ -584,7 +614,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             const float sq = disc_attempt_sq(g[j], w[j]);
             need_m[j] = live_m[j] & ~lanes_where(sq < 1.0f);
         }
-        coop_finish2m<2>(lds, 0, need_m, g, w, tid);
+        coop_finish2m<2, POW2>(lds, 0, need_m, g, w, tid);
 
         float rdx[kSets], rdy[kSets], rdz[kSets];
         lanemask hit_m[kSets];
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             }
         }
         // (the per-block switch between one and two in-wave attempts: see the bool form below)
-        const int stragglers = __builtin_amdgcn_readfirstlane(coop_finish2m<3>(lds, 1, need_m, g, w, tid));
+        const int stragglers = __builtin_amdgcn_readfirstlane(coop_finish2m<3, POW2>(lds, 1, need_m, g, w, tid));
         if (sphere_trips == kCoopTrips2 && stragglers > kCoopCap + RF_ADAPT_ON)
             sphere_trips = kCoopTrips2 + 1;
         else if (sphere_trips != kCoopTrips2 && 2 * stragglers < kCoopCap + RF_ADAPT_OFF)
