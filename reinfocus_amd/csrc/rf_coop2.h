@@ -468,7 +468,9 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
 #pragma unroll
     for (int j = 0; j < kSets; ++j) {
         if (lane_in(parked[j])) {
-            const uint4 ps = *entry16(state, slot[j]);
+            uint4 ps = *entry16(state, slot[j]);
+            // (opaque: or the first draw's 64-bit sum is fed by a second, 8-byte read of the same entry)
+            asm volatile("" : "+v"(ps.x), "+v"(ps.y), "+v"(ps.z), "+v"(ps.w));
             g[j] = Rng{ps.x, ps.y, ps.z, ps.w};
             const uint4 w4 = *entry16(lds.words4, slot[j]);
             static_assert(RF_WORDS_LOHI, "entry layout");
