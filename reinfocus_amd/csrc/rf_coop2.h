@@ -484,6 +484,87 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
     return stragglers;
 }
 
+// Disc tails without the block: every wave packs the stragglers of its own three pixel sets (3 x 64 x 0.215 = 41 on
+// average) onto its first lanes through its quarter of state[0], finishes them there and hands the results back --
+// all of it inside the wave, in LDS order, with no barrier (the block-wide form costs two per sample and makes every
+// wave wait for the slowest worker).  An entry's 16 bytes carry the state to the worker, the advanced state back, and
+// then the accepted draws' four words back (two round trips through the same slot: the sphere phase of the previous
+// sample may still be read from every other array by slower waves).  Stragglers beyond the 64 slots finish in place.
+// Measured per kernel instance (profiles/r03_ab.txt): +1.5 % at 256 px, +2.5 % at 512 px; the instances for other
+// frame sizes (float64 pixel coordinates: more registers, more issue-bound) spill with it and lose 1.2 %, so they keep
+// the block-wide call.  RF_DISC_WAVE: 1 / 0 = everywhere / nowhere, -1 = power-of-two frames only.
+#ifndef RF_DISC_WAVE
+#define RF_DISC_WAVE -1
+#endif
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&need)[kSets], Rng (&g)[kSets],
+                                                uint32_t (&w)[kSets][6], int tid)
+{
+    // region = the block's state[0]; this wave's entries are [wbase, wbase + 64) (a scalar: folded into the slots)
+    const int wbase = __builtin_amdgcn_readfirstlane(tid) & ~63;
+    int total = 0, first[kSets];
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        first[j] = total;
+        total += (int)__builtin_popcountll(need[j]);
+    }
+    if (total == 0) // wave-uniform
+        return;
+    int slot[kSets];
+    lanemask packed[kSets];
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need[j] >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((unsigned)need[j], 0));
+        slot[j] = (wbase + first[j] + rank) * 16; // byte offset of the entry
+        packed[j] = need[j] & lanes_where(slot[j] < (wbase + 64) * 16);
+        if (lane_in(packed[j]))
+            *entry16(region, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
+        if (lane_in(need[j] & ~packed[j])) { // more than 64 stragglers in one wave (p ~ 1e-5): in place
+            while (!disc_attempt(g[j], w[j])) {
+            }
+        }
+    }
+    wave_lds_order();
+    const bool worker = tid < wbase + min(total, 64);
+    Rng wg{0, 0, 0, 0};
+    if (worker) {
+        const uint4 ps = region[tid];
+        wg = Rng{ps.x, ps.y, ps.z, ps.w};
+        uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
+        while (!disc_attempt(wg, ww)) {
+        }
+        region[tid] = RF_WORDS4(ww); // the accepted draws first: the worker keeps the four state words meanwhile
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        if (lane_in(packed[j])) {
+            const uint4 w4 = *entry16(region, slot[j]);
+            static_assert(RF_WORDS_LOHI, "entry layout");
+            w[j][1] = w4.x; w[j][0] = w4.y; w[j][3] = w4.z; w[j][2] = w4.w;
+        }
+    }
+    wave_lds_order();
+    if (worker)
+        region[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
+    wave_lds_order();
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) {
+        if (lane_in(packed[j])) {
+            uint4 ps = *entry16(region, slot[j]);
+            asm volatile("" : "+v"(ps.x), "+v"(ps.y), "+v"(ps.z), "+v"(ps.w));
+            g[j] = Rng{ps.x, ps.y, ps.z, ps.w};
+        }
+    }
+    wave_lds_order(); // (the next sample's stragglers overwrite the slots)
+}
+
 template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW>
 __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
@@ -616,7 +697,10 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
             const float sq = disc_attempt_sq(g[j], w[j]);
             need_m[j] = live_m[j] & ~lanes_where(sq < 1.0f);
         }
-        coop_finish2m<2, POW2>(lds, 0, need_m, g, w, tid);
+        if (RF_DISC_WAVE < 0 ? POW2 : RF_DISC_WAVE != 0)
+            disc_tails_wave(lds.state[0], need_m, g, w, tid);
+        else
+            coop_finish2m<2, POW2>(lds, 0, need_m, g, w, tid);
 
         float rdx[kSets], rdy[kSets], rdz[kSets];
         lanemask hit_m[kSets];
