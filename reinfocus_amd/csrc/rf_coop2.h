@@ -24,6 +24,11 @@
 //    (the rest finish in place), so each block watches its own count and returns to two in-wave
 //    attempts while its list would overflow: 146.3, and 121.6 at 300 px / 100 spp (always one:
 //    147.0 / 107.7; always two: 142.5 / 119.5).
+//
+// Round 3 (k env-steps/s on the driver's metric): lane predicates as scalar-register masks
+// (RF_MASKS: 145.8 -> 150.7), worker waves at s_setprio 1 (RF_TAIL_PRIO: -> 155.5), list slots by one LDS atomic per
+// wave for power-of-two frames (RF_PARK_WAVE: -> 157.8), disc tails inside the wave for power-of-two frames
+// (RF_DISC_WAVE, disc_tails_wave: 3 barriers per sample instead of 5, -> 159.9).
 #pragma once
 
 #include "rf_kernels.h"
