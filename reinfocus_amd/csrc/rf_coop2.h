@@ -501,6 +501,11 @@ __device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lan
 #ifndef RF_DISC_WAVE
 #define RF_DISC_WAVE -1
 #endif
+#ifndef RF_DISC_WAVE_SLOTS
+#define RF_DISC_WAVE_SLOTS 64 // entries per wave; tests build an 8-entry form to exercise the in-place path
+#endif
+constexpr int kDiscWaveSlots = RF_DISC_WAVE_SLOTS;
+static_assert(kDiscWaveSlots >= 1 && kDiscWaveSlots <= 64, "a wave's quarter of state[0]");
 __device__ __forceinline__ void wave_lds_order()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -527,16 +532,16 @@ __device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need[j] >> 32),
                                                         __builtin_amdgcn_mbcnt_lo((unsigned)need[j], 0));
         slot[j] = (wbase + first[j] + rank) * 16; // byte offset of the entry
-        packed[j] = need[j] & lanes_where(slot[j] < (wbase + 64) * 16);
+        packed[j] = need[j] & lanes_where(slot[j] < (wbase + kDiscWaveSlots) * 16);
         if (lane_in(packed[j]))
             *entry16(region, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
-        if (lane_in(need[j] & ~packed[j])) { // more than 64 stragglers in one wave (p ~ 1e-5): in place
+        if (lane_in(need[j] & ~packed[j])) { // more stragglers in one wave than slots (p ~ 1e-5 with 64): in place
             while (!disc_attempt(g[j], w[j])) {
             }
         }
     }
     wave_lds_order();
-    const bool worker = tid < wbase + min(total, 64);
+    const bool worker = tid < wbase + min(total, kDiscWaveSlots);
     Rng wg{0, 0, 0, 0};
     if (worker) {
         const uint4 ps = region[tid];

@@ -403,13 +403,15 @@ def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
     return got["frames"], got["states"]
 
 
-@pytest.mark.parametrize("h", [96, 100])
+@pytest.mark.parametrize("h", [96, 100, 128])
 def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path, h):
     """render_kernel_coop2 packs the stragglers of a block into a 256-entry list and lets the
-    ones that do not fit finish in their own wave.  With the production capacity that path is
-    practically never taken, so tests/gpucheck builds the same library with a 32-entry list
-    (every all-hit block overflows) and a child process renders with it: frames and RNG states
-    must equal the oracle's, i.e. the production build's."""
+    ones that do not fit finish in their own wave; for power-of-two frames (h = 128) the disc
+    stragglers of a wave go into 64 slots of its own instead.  With the production capacities
+    those overflow paths are practically never taken, so tests/gpucheck builds the same library
+    with a 32-entry list (every all-hit block overflows) and 8 slots per wave (every wave
+    overflows), and a child process renders with it: frames and RNG states must equal the
+    oracle's, i.e. the production build's."""
     import subprocess
 
     so = helpers.built("tests/gpucheck", "libreinfocus_cap32.so")
