@@ -74,11 +74,17 @@ constexpr int kCoopTrips2 = RF_COOP2_TRIPS; // in-wave sphere attempts before th
 #ifndef RF_ADAPT_OFF
 #define RF_ADAPT_OFF -32
 #endif
+#ifndef RF_NW
+#define RF_NW 4 // waves per block of render_kernel_coop2 (2: measured; the host then takes the two-wave-wide layouts)
+#endif
+constexpr int kBlock2 = 64 * RF_NW; // threads per block of render_kernel_coop2
+static_assert(RF_NW == 2 || RF_NW == 4, "tile layouts exist for two and four waves");
+using CoopLds2 = CoopLdsT<kBlock2>;
 #ifndef RF_COOP_CAP
-#define RF_COOP_CAP kBlock // entries of the packed list; tests build a 32-entry one to stress the overflow path
+#define RF_COOP_CAP kBlock2 // entries of the packed list; tests build a 32-entry one to stress the overflow path
 #endif
 constexpr int kCoopCap = RF_COOP_CAP;
-static_assert(kCoopCap >= 1 && kCoopCap <= kBlock, "the packed list lives in CoopLds");
+static_assert(kCoopCap >= 1 && kCoopCap <= kBlock2, "the packed list lives in CoopLds2");
 #ifndef RF_COLOUR_LDS
 #define RF_COLOUR_LDS 2
 #endif
@@ -160,7 +166,7 @@ __device__ __forceinline__ uint4 *entry16(uint4 *array, int offset)
 #define RF_TAIL_PRIO_R2_ONLY 0
 #endif
 template <int DIM>
-__device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total, int tid)
+__device__ __forceinline__ void coop_workers(CoopLds2 &lds, int parity, int total, int tid)
 {
     uint4 *const state = lds.state[parity];
 #if RF_TAIL_PRIO && !RF_TAIL_PRIO_R2_ONLY
@@ -284,7 +290,7 @@ __device__ __forceinline__ void coop_workers(CoopLds &lds, int parity, int total
 // arrays of CoopLds); stragglers that do not fit finish their loop in their own wave.  Returns
 // the number of stragglers the block had (block-uniform).
 template <int DIM>
-__device__ __forceinline__ int coop_finish2(CoopLds &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
+__device__ __forceinline__ int coop_finish2(CoopLds2 &lds, int parity, bool (&need)[kSets], Rng (&g)[kSets],
                                             uint32_t (&w)[kSets][6], int tid)
 {
     asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
@@ -412,7 +418,7 @@ __device__ __forceinline__ lanemask lanes_where(bool p) { return __builtin_amdgc
 // instance (profiles/r03_ab.txt): power-of-two frames +1.0 ... +1.7 % (128 / 256 / 512 px), the others, whose float64
 // pixel coordinates leave them more issue-bound, -1.3 ... -2.3 % (300 / 384 / 600 px): the kernel takes it for POW2.
 template <int DIM, bool WAVE_SLOTS>
-__device__ __forceinline__ int coop_finish2m(CoopLds &lds, int parity, const lanemask (&need)[kSets], Rng (&g)[kSets],
+__device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, const lanemask (&need)[kSets], Rng (&g)[kSets],
                                              uint32_t (&w)[kSets][6], int tid)
 {
     asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
@@ -576,19 +582,20 @@ __device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&
 }
 
 template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW>
-__global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
+__global__ __launch_bounds__(kBlock2, RF_SETS_OCC) void render_kernel_coop2(RenderArgs a)
 {
     // tile of a block: WX waves (of WW x 64 / WW pixels) side by side, 4 / WX down, kSets sets
     constexpr int tWaveW = WW, tWaveH = 64 / WW;
-    constexpr int tWavesX = WX, tTileW = WX * tWaveW, tTileH = (4 / WX) * tWaveH, tTileH2 = tTileH * kSets;
-    __shared__ CoopLds lds;
+    static_assert(WX <= RF_NW, "waves side by side");
+    constexpr int tWavesX = WX, tTileW = WX * tWaveW, tTileH = (RF_NW / WX) * tWaveH, tTileH2 = tTileH * kSets;
+    __shared__ CoopLds2 lds;
     // the frame staging buffer (kSets * 768 B) reuses the words4 array once the sample loop is over
-    static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock * 3, "stage does not fit");
+    static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock2 * 3, "stage does not fit");
     uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.words4);
 #if RF_COLOUR_LDS > 0
     // colour accumulators of the first RF_COLOUR_LDS pixel sets live in LDS (one read-modify-write
     // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
-    __shared__ float lds_colour[RF_COLOUR_LDS][3][kBlock];
+    __shared__ float lds_colour[RF_COLOUR_LDS][3][kBlock2];
 #endif
 
     const int e = blockIdx.y;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
     const unsigned mirror_mask = mirror ? (unsigned)(tWavesX - 1) : 0u;
     auto geometry = [&](int t) {
         // (unsigned masks and shifts: the signed / and % of the same powers of two cost sign fix-ups every iteration)
-        __builtin_assume(t >= 0 && t < kBlock); // (the per-iteration index is opaque: without this, bits 8.. are computed with)
+        __builtin_assume(t >= 0 && t < kBlock2); // (the per-iteration index is opaque: without this, bits 8.. are computed with)
         const unsigned ut = (unsigned)t, wv = ut >> 6, lane = ut & 63u;
         const unsigned wq = wv & (unsigned)(tWavesX - 1);
         // mirrored blocks count their waves from the right: (tWavesX - 1) - wq == wq ^ (tWavesX - 1), a block-uniform mask
@@ -913,7 +920,7 @@ __global__ __launch_bounds__(kBlock, RF_SETS_OCC) void render_kernel_coop2(Rende
         // the tile's rows (tTileW * 3 B each) -> LDS -> coalesced dword stores per row
         __syncthreads();
         constexpr int kRowDw = tTileW * 3 / 4;
-        for (int i = tid; i < tTileH2 * kRowDw; i += kBlock) {
+        for (int i = tid; i < tTileH2 * kRowDw; i += kBlock2) {
             const int r = i / kRowDw, d = i - r * kRowDw;
             const int yy = tile_y * tTileH2 + r;
             const int valid_dw = min(tTileW, a.w - tile_x * tTileW) * 3 / 4; // w % 4 == 0

@@ -129,14 +129,16 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
 // The state buffer is doubled because a fast wave parks the stragglers of the next call while
 // a slow one is still collecting; the draws are only written after the next call's first
 // barrier, and the counter of this parity is next touched two calls later.
-struct CoopLds {
-    uint4 state[2][kBlock];
-    uint4 words4[kBlock];
-    uint2 words2[kBlock];
-    uint16_t owner[kBlock]; // render_kernel_coop2: original slot of a re-packed entry
+template <int N>
+struct CoopLdsT {
+    uint4 state[2][N];
+    uint4 words4[N];
+    uint2 words2[N];
+    uint16_t owner[N]; // render_kernel_coop2: original slot of a re-packed entry
     int cnt[2];
-    int cnt2;               // render_kernel_coop2: entries in the second round
+    int cnt2;          // render_kernel_coop2: entries in the second round
 };
+using CoopLds = CoopLdsT<kBlock>;
 
 template <int DIM>
 __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need, Rng &g, uint32_t *w)
