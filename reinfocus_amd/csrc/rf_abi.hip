@@ -546,14 +546,10 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             //   A 128 x 6  (WX 4, WW 32)   B 64 x 12 (2, 32)   C 256 x 3 (4, 64)   D 128 x 6 (2, 64)
             // see pick_tile_layout.
             const int layout = ctx->tile_layout >= 0 ? ctx->tile_layout : pick_tile_layout(h, w, ctx->hit_fraction);
-#if RF_NW == 4
             static const int kLayoutWX[6] = {4, 2, 4, 2, 4, 2};
-#else // two-wave blocks (an experiment's build): the two-wave-wide form of every layout
-            static const int kLayoutWX[6] = {2, 2, 2, 2, 2, 2};
-#endif
             static const int kLayoutWW[6] = {32, 32, 64, 64, 16, 16};
             const int layout_w = kLayoutWX[layout] * kLayoutWW[layout],
-                      layout_h = (RF_NW / kLayoutWX[layout]) * (64 / kLayoutWW[layout]) * rf::kSets;
+                      layout_h = (4 / kLayoutWX[layout]) * (64 / kLayoutWW[layout]) * rf::kSets;
             const dim3 tiles2(((w + layout_w - 1) / layout_w) * ((h + layout_h - 1) / layout_h), ne);
             const dim3 block2(rf::kBlock2);
             const bool lens32 = a.cs.lens_f32 != 0;
@@ -561,7 +557,6 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
     hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW>), tiles2, block2, 0, ctx->stream, b);         \
     ctx->render_kernel = "render_kernel_coop2<" #P ", " #L ", " #WX ", " #WW ">"
-#if RF_NW == 4
 #define RF_LAUNCH2(P, L)                                                                                   \
     do {                                                                                                   \
         switch (layout) {                                                                                  \
@@ -573,16 +568,6 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         default: RF_LAUNCH2_ONE(P, L, 2, 16); break;                                                       \
         }                                                                                                  \
     } while (0)
-#else
-#define RF_LAUNCH2(P, L)                                                                                   \
-    do {                                                                                                   \
-        switch (layout) {                                                                                  \
-        case 0: case 1: RF_LAUNCH2_ONE(P, L, 2, 32); break;                                                \
-        case 2: case 3: RF_LAUNCH2_ONE(P, L, 2, 64); break;                                                \
-        default: RF_LAUNCH2_ONE(P, L, 2, 16); break;                                                       \
-        }                                                                                                  \
-    } while (0)
-#endif
                 if (pow2 && lens32)
                     RF_LAUNCH2(true, 1);
                 else if (pow2)
