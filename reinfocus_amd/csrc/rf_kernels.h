@@ -165,11 +165,6 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
         const uint4 ps = state[tid];
         Rng wg{ps.x, ps.y, ps.z, ps.w};
         uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-#ifdef RF_WORKER_MAXTRIPS // timing experiment only: truncated tails, wrong frames
-        for (int trip = 0; trip < RF_WORKER_MAXTRIPS; ++trip)
-            if (DIM == 2 ? disc_attempt(wg, ww) : sphere_attempt(wg, ww))
-                break;
-#else
         if (DIM == 2) {
             while (!disc_attempt(wg, ww)) {
             }
@@ -177,7 +172,6 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
             while (!sphere_attempt(wg, ww)) {
             }
         }
-#endif
         state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
         lds.words4[tid] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
         if (DIM == 3)
@@ -198,16 +192,7 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
     }
 }
 
-#ifndef RF_STAGE
-#define RF_STAGE 3
-#endif
-#ifndef RF_COOP_TRIPS
-#define RF_COOP_TRIPS 2
-#endif
-#ifndef RF_COOP_DISC
-#define RF_COOP_DISC 1 // in-wave disc attempts before the cooperative tail; 0 = disc loop stays in-wave
-#endif
-constexpr int kCoopTrips = RF_COOP_TRIPS;
+constexpr int kCoopTrips = 2; // in-wave sphere attempts before the cooperative tail (the disc loop makes one)
 
 // Pixel <-> lane mapping of the cooperative kernel: a wave owns kWaveW x kWaveH pixels and a
 // block kWavesX x (4 / kWavesX) waves.  The mapping only changes which thread owns a pixel,
@@ -265,44 +250,16 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
     for (int k = 0; k < a.spp; ++k) {
         float s, t;
         sample_coords<POW2>(g, x, y, xf, yf, a.h64, a.w64, a.inv_w, a.inv_h, a.rw64, a.rh64, s, t);
-#if RF_STAGE == 0 // timing experiments only (tools/ab.sh): truncated sample pipelines
-        const Colour c{s, t, 0.0f};
-#elif RF_STAGE == 1
         uint32_t w[6] = {0, 0, 0, 0, 0, 0};
         bool dneed = live;
-        if (dneed && disc_attempt(g, w))
-            dneed = false;
-        coop_finish<2>(lds, 0, dneed, g, w);
-        float p0, p1;
-        disc_finish(w, p0, p1);
-        const Colour c{s + p0, t + p1, 0.0f};
-#elif RF_STAGE == 2
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-        bool dneed = live;
-        if (dneed && disc_attempt(g, w))
-            dneed = false;
-        coop_finish<2>(lds, 0, dneed, g, w);
-        float p0, p1;
-        disc_finish(w, p0, p1);
-        const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs, s, t, a.tab);
-        const Colour c = sample_axis_shade(pre, p0, p1, s);
-#else
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-#if RF_COOP_DISC
-        bool dneed = live;
-        for (int trip = 0; trip < RF_COOP_DISC; ++trip) {
-            if (__any(dneed)) {
-                if (dneed && disc_attempt(g, w))
-                    dneed = false;
-            }
+        if (__any(dneed)) {
+            if (dneed && disc_attempt(g, w))
+                dneed = false;
         }
         coop_finish<2>(lds, 0, dneed, g, w);
         float p0, p1;
         disc_finish(w, p0, p1);
         const AxisPre pre = sample_axis_ray(p0, p1, env, a.cs, s, t, a.tab);
-#else
-        const AxisPre pre = sample_axis_pre(g, env, a.cs, s, t, a.tab);
-#endif
 
         bool need = live && pre.hit;
         for (int trip = 0; trip < kCoopTrips; ++trip) {
@@ -317,7 +274,6 @@ __global__ __launch_bounds__(kBlock) void render_kernel_coop(RenderArgs a)
         if (pre.hit)
             sphere_finish(w, q0, q1, q2);
         const Colour c = sample_axis_shade(pre, q0, q1, q2);
-#endif
         cr = add2(cr, c.r);
         cg = add2(cg, c.g);
         cb = add2(cb, c.b);
