@@ -50,9 +50,12 @@ def parse_args(argv=None):
     ap.add_argument("--frame", type=int, default=256)
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--cpu-baseline-envs", type=int, default=0, help="0 = choose ~12 s of CPU work")
-    ap.add_argument("--env", choices=["device", "host"], default="device",
+    ap.add_argument("--env", choices=["device", "host", "literal"], default="device",
                     help="device: whole step resident on the GPU (rf_env_*); host: numpy glue around "
-                         "rf_render / rf_focus (identical results, tests/test_gpu_environment.py)")
+                         "rf_render / rf_focus on frames that stay in HBM; literal: the same glue over "
+                         "INTEGRATION.md's literal stub -- rf_render(host_out) -> numpy array -> rf_upload_frames + "
+                         "rf_focus, i.e. every frame crosses PCIe twice per render (identical results, "
+                         "tests/test_gpu_environment.py)")
     ap.add_argument("--sharded-env", action="store_true",
                     help="one process: harness.ShardedVectorDiscreteSteps over --gpus devices (threads), instead "
                          "of one process per GPU")
@@ -111,11 +114,11 @@ def launch_ranks(world, argv, total_timeout=None):
             except subprocess.TimeoutExpired:
                 pass
 
-    class Interrupted(Exception):
-        pass
+    interrupted = []  # signals received: the handler only records them, the poll loop acts (an exception raised
+                      # from the handler could fire inside the clean-up itself and leave ranks behind)
 
     def on_signal(signum, frame):
-        raise Interrupted(signum)
+        interrupted.append(signum)
 
     previous = {}
     for signum in (signal.SIGTERM, signal.SIGINT):
@@ -146,6 +149,10 @@ def launch_ranks(world, argv, total_timeout=None):
         pending = set(range(world))
         failed_at = None
         while pending:
+            if interrupted:
+                print(f"bench.py: launcher got signal {interrupted[0]}, ending the ranks", file=sys.stderr)
+                worst = 128 + int(interrupted[0])
+                break
             for rank in sorted(pending):
                 rc = children[rank].poll()
                 if rc is None:
@@ -165,12 +172,10 @@ def launch_ranks(world, argv, total_timeout=None):
                 end_children()
                 pending.clear()
             time.sleep(0.05)
-        pump.join(timeout=5.0)
-    except Interrupted as stop:
-        print(f"bench.py: launcher got signal {stop.args[0]}, ending the ranks", file=sys.stderr)
-        worst = 128 + int(stop.args[0])
+        if not interrupted:
+            pump.join(timeout=5.0)
     finally:
-        end_children()
+        end_children()  # (further signals only append to `interrupted`: nothing can cut this short)
         for signum, handler in previous.items():
             signal.signal(signum, handler)
     return worst if 0 <= worst < 256 else 1
@@ -216,6 +221,14 @@ class Ranks:
         t = torch.tensor([float(value)], dtype=torch.float64)
         self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return float(t.item())
+
+    def gather(self, item):
+        """Every rank's `item` (any picklable object), in rank order, on every rank."""
+        if self.dist is None:
+            return [item]
+        items = [None] * self.world
+        self.dist.all_gather_object(items, item)
+        return items
 
     def close(self):
         if self.dist is not None:
@@ -413,6 +426,54 @@ def baseline_config_name(envs_per_gpu, frame, spp, n_gpus):
     return "not a BASELINE.json configuration"
 
 
+def rank_placement(rank, device, native=None):
+    """Where this rank runs: HIP device index, the GPU's PCI bus id and NUMA node (rf_device_info), and the CPUs the
+    whole process -- the HIP runtime's helper threads included -- was restricted to: those of that NUMA node
+    (REINFOCUS_BENCH_NO_PIN=1 leaves the affinity alone).  Without `native` (the plumbing test, no GPU) the row comes
+    from REINFOCUS_BENCH_FAKE_DEVICES = "busid@node,busid@node,..." indexed by rank."""
+    import socket
+
+    if native is None:
+        table = [entry.split("@") for entry in os.environ.get("REINFOCUS_BENCH_FAKE_DEVICES", "").split(",") if entry]
+        bus, node = table[rank % len(table)] if table else (f"fake:{rank:02x}:00.0", "-1")
+        info = {"device": device, "pci_bus_id": bus, "numa_node": int(node)}
+        cpus = None
+    else:
+        info = native.device_info(device)
+        cpus = (None if os.environ.get("REINFOCUS_BENCH_NO_PIN") == "1"
+                else native.pin_to_numa_node(info["numa_node"], whole_process=True))
+    try:
+        now = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        now = None
+    return dict(info, rank=rank, host=socket.gethostname(), pinned=cpus is not None, cpus=compact_ranges(now))
+
+
+def compact_ranges(values):
+    """[0, 1, 2, 3, 8, 9] -> "0-3,8-9" (a rank's CPU set in the JSON line)."""
+    if not values:
+        return None
+    runs, start, prev = [], values[0], values[0]
+    for v in values[1:] + [None]:
+        if v is None or v != prev + 1:
+            runs.append(str(start) if start == prev else f"{start}-{prev}")
+            start = v
+        prev = v
+    return ",".join(runs)
+
+
+def check_distinct_devices(rows, allow_shared):
+    """An N-GPU line has to come from N distinct GPUs (of one host): returns an error string or None."""
+    seen = {}
+    for row in rows:
+        key = (row.get("host"), row["pci_bus_id"])
+        if key in seen and not allow_shared:
+            return (f"ranks {seen[key]} and {row['rank']} both ran on the GPU at {row['pci_bus_id']}: not an "
+                    f"{len(rows)}-GPU measurement (REINFOCUS_BENCH_DEVICE allows it for rehearsals)")
+        seen.setdefault(key, row["rank"])
+    return None
+
+
 def shard_plan(rank, envs_per_gpu, frame):
     """Rank r owns global envs [r*E, (r+1)*E) and therefore the RNG states a single-device
     run of all envs would use for them (pixel index = e*h*w + y*w + x, render.py:217)."""
@@ -544,15 +605,39 @@ def main(argv=None):
         common = dict(num_envs=n_here, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank)
         if args.sharded_env:
             devices = [int(pinned)] * args.gpus if pinned is not None else list(range(args.gpus))
-            env = harness.ShardedVectorDiscreteSteps(devices=devices, **common)
+            env = harness.ShardedVectorDiscreteSteps(devices=devices, numa_pin=os.environ.get("REINFOCUS_BENCH_NO_PIN") != "1",
+                                                     **common)
             contexts = [shard.ctx for shard in env._shards]
+            placements = [dict(p, rank=g, host=os.uname().nodename, pinned=p["cpus"] is not None,
+                               cpus=compact_ranges(p["cpus"])) for g, p in enumerate(env.placements)]
         else:
-            env_cls = harness.DeviceVectorDiscreteSteps if args.env == "device" else harness.VectorDiscreteSteps
-            env = env_cls(device=device, first_state_index=plan["first_state_index"], **common)
-            contexts = [env._ctx if args.env == "device" else env._renderer._ctx]
+            # which physical GPU, and this process on that GPU's NUMA node, before the context (its stream, its pinned
+            # staging buffers, the environment's host arrays) exists
+            placements = [rank_placement(ranks.rank, device, _native)]
+            if args.env == "device":
+                env = harness.DeviceVectorDiscreteSteps(device=device, first_state_index=plan["first_state_index"], **common)
+                contexts = [env._ctx]
+            else:
+                env = harness.VectorDiscreteSteps(device=device, first_state_index=plan["first_state_index"],
+                                                  host_frames=args.env == "literal", **common)
+                contexts = [env._renderer._ctx]
+                if args.env == "literal":  # host arrays are scored on vision's scratch context
+                    from reinfocus_amd import vision
+
+                    contexts.append(vision._scratch_context())
         ctx = contexts[0]
         env.reset()
         pixels_before_first_step = _native.pixels_rendered()
+    else:
+        placements = [rank_placement(ranks.rank, ranks.local_rank)]
+    if not args.sharded_env:
+        placements = [row for rows in ranks.gather(placements) for row in rows]
+    shared_gpu = check_distinct_devices(placements, allow_shared=os.environ.get("REINFOCUS_BENCH_DEVICE") is not None)
+    if shared_gpu:
+        if env is not None:
+            env.close()
+        ranks.close()
+        raise SystemExit("bench.py: " + shared_gpu)
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
     def one_step():
@@ -566,27 +651,41 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_step()
 
+    def on_contexts(call):
+        if args.sharded_env:
+            env._each(lambda shard: call(shard.ctx))
+        else:
+            for c in contexts:
+                call(c)
+
     if env is not None:
-        for c in contexts:
-            if not args.no_kernel_timing:
-                c.timing(True)
-            c.synchronize()
+        if not args.no_kernel_timing:
+            on_contexts(lambda c: c.timing(True))
+        on_contexts(lambda c: c.synchronize())
     ranks.barrier()
     t0 = time.perf_counter()
     resets = 0
     for _ in range(args.steps):
         resets += one_step()
     if env is not None:
-        for c in contexts:
-            c.synchronize()
+        on_contexts(lambda c: c.synchronize())
     elapsed_local = time.perf_counter() - t0
     ranks.barrier()
     elapsed = ranks.reduce(elapsed_local, "MAX")
     total_resets = ranks.reduce(resets, "SUM")
 
-    timing = ctx.timing_read() if env is not None and not args.no_kernel_timing else None
-    all_kernel_ms = (sum(sum(c.timing_read()[k] for k in ("render_ms", "focus_ms")) for c in contexts)
-                     if timing is not None else None)
+    timing = None
+    if env is not None and not args.no_kernel_timing:
+        if args.sharded_env:
+            timing = env._each(lambda shard: shard.ctx.timing_read())[0]
+        else:  # (the literal route renders on one context and scores on another)
+            reads = [c.timing_read() for c in contexts]
+            timing = {key: sum(r[key] for r in reads) for key in reads[0]}
+    if timing is not None and args.sharded_env:  # (a shard's context is only ever touched from its own thread)
+        all_kernel_ms = sum(sum(t[k] for k in ("render_ms", "focus_ms"))
+                            for t in env._each(lambda shard: shard.ctx.timing_read()))
+    else:
+        all_kernel_ms = sum(timing[k] for k in ("render_ms", "focus_ms")) if timing is not None else None
     n_gpus = args.gpus if args.sharded_env else ranks.world
     total_envs = n_local * n_gpus
     value = total_envs * args.steps / elapsed if env is not None else None
@@ -617,9 +716,16 @@ def main(argv=None):
                 "sharding": ("one process, one rf_ctx + host thread per GPU (ShardedVectorDiscreteSteps)"
                              if args.sharded_env else "one process per GPU, independent env ranges") +
                             ", no data-path collective",
-                "env_glue": "device-resident (rf_env_step)" if args.env == "device" else "host numpy (harness)",
+                "env_glue": {"device": "device-resident (rf_env_step)", "host": "host numpy (harness), frames stay in HBM",
+                             "literal": "host numpy (harness) over the literal stub: rf_render(host_out) + "
+                                        "rf_upload_frames + rf_focus, frames cross PCIe twice per render"}[args.env],
             },
+            # one row per rank (per shard with --sharded-env): an N-GPU value comes from N distinct GPUs
+            "devices": placements,
         }
+        if args.env == "literal" and env is not None:
+            per_step = n_local * frame * frame * 3 * (1.0 + total_resets / max(args.steps, 1) / max(total_envs, 1))
+            out["pcie_bytes_per_step_per_gpu"] = {"device_to_host": per_step, "host_to_device": per_step}
         if env is not None:
             # every render launch of this process used the same kernel instance when the 13-environment
             # extrema render (cached_focus_extrema: same frame size and sample count) is among them
@@ -668,7 +774,7 @@ def main(argv=None):
             if pmc_failure:
                 out["roofline"]["pmc_failure"] = pmc_failure
             out["focus_kernel"] = {
-                "achieved_GBps": FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9,
+                "achieved_GBps": FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9 if focus_s > 0 else None,
                 "avg_launch_ms": timing["focus_ms"] / max(timing["focus_launches"], 1),
                 "launches": timing["focus_launches"],
             }

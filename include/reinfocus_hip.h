@@ -49,6 +49,12 @@ int rf_abi_version(void);
 /* Number of visible HIP devices (0 on a CPU-only host; never fails the process). */
 int rf_device_count(int *count);
 
+/* Which physical GPU `device` is: its PCI bus id ("0000:c1:00.0", NUL-terminated, into bus_id[len], len >= 16)
+ * and the NUMA node the host reports for it (/sys/bus/pci/devices/<id>/numa_node; -1 if unknown).
+ * No reference counterpart (the reference is single-device): bench.py prints one row per rank so that an
+ * N-GPU line proves it ran on N distinct GPUs, and ranks / shard threads pin themselves to their GPU's node. */
+int rf_device_info(int device, char *bus_id, int len, int *numa_node);
+
 /* Creates the per-renderer context on `device`.
  * Replaces: FastRenderer.__init__ device-side state (graphics/render.py:127-145). */
 int rf_create(int device, rf_ctx **out);

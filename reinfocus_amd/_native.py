@@ -29,6 +29,7 @@ SYMBOLS = (
     "rf_last_error",
     "rf_abi_version",
     "rf_device_count",
+    "rf_device_info",
     "rf_create",
     "rf_destroy",
     "rf_seed",
@@ -116,6 +117,7 @@ def load():
     lib.rf_last_error.argtypes = []
     lib.rf_abi_version.argtypes = []
     lib.rf_device_count.argtypes = [ctypes.POINTER(i32)]
+    lib.rf_device_info.argtypes = [i32, ctypes.c_char_p, i32, ctypes.POINTER(i32)]
     lib.rf_create.argtypes = [i32, ctypes.POINTER(vp)]
     lib.rf_destroy.argtypes = [vp]
     lib.rf_seed.argtypes = [vp, u64, u64, u64]
@@ -169,6 +171,51 @@ def device_count():
     n = ctypes.c_int(0)
     _check(load().rf_device_count(ctypes.byref(n)))
     return n.value
+
+
+def device_info(device):
+    """{"device", "pci_bus_id", "numa_node"} of a HIP device index (rf_device_info); numa_node is -1 when the
+    host does not say."""
+    bus = ctypes.create_string_buffer(32)
+    node = ctypes.c_int(-1)
+    _check(load().rf_device_info(int(device), bus, 32, ctypes.byref(node)))
+    return {"device": int(device), "pci_bus_id": bus.value.decode(), "numa_node": node.value}
+
+
+def numa_cpus(node, sysfs="/sys/devices/system/node"):
+    """CPUs of a NUMA node ("0-15,128-143" in <sysfs>/node<N>/cpulist) as a set; empty if unknown."""
+    cpus = set()
+    try:
+        text = open(os.path.join(sysfs, f"node{int(node)}", "cpulist")).read().strip()
+    except (OSError, ValueError):
+        return cpus
+    for part in filter(None, text.split(",")):
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_numa_node(node, whole_process=False, sysfs="/sys/devices/system/node"):
+    """Restricts the calling thread (or every thread of the process: the HIP runtime's helper threads exist by the
+    time a device can be asked where it sits) to the CPUs of `node` that the process may use at all.  Returns the
+    sorted CPU list now in force, or None when nothing was changed (unknown node, no such CPUs, no permission)."""
+    if node is None or int(node) < 0 or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = numa_cpus(node, sysfs) & set(os.sched_getaffinity(0))
+    if not allowed:
+        return None
+    try:
+        tasks = [int(t) for t in os.listdir("/proc/self/task")] if whole_process else [0]
+    except OSError:
+        tasks = [0]
+    changed = False
+    for task in tasks:
+        try:
+            os.sched_setaffinity(task, allowed)
+            changed = True
+        except OSError:  # a thread that has ended meanwhile, or no permission
+            pass
+    return sorted(allowed) if changed else None
 
 
 def pixels_rendered():

@@ -298,6 +298,27 @@ int rf_device_count(int *count)
     return RF_OK;
 }
 
+int rf_device_info(int device, char *bus_id, int len, int *numa_node)
+{
+    RF_REQUIRE(bus_id != nullptr && numa_node != nullptr && len >= 16, "rf_device_info: bus_id[>= 16] and numa_node wanted");
+    int n = 0;
+    RF_HIP(hipGetDeviceCount(&n));
+    RF_REQUIRE(device >= 0 && device < n, "rf_device_info: device %d of %d", device, n);
+    RF_HIP(hipDeviceGetPCIBusId(bus_id, len, device));
+    for (char *c = bus_id; *c; ++c) // sysfs spells the id in lower case
+        *c = (*c >= 'A' && *c <= 'F') ? (char)(*c - 'A' + 'a') : *c;
+    *numa_node = -1;
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus_id);
+    if (FILE *f = fopen(path, "r")) {
+        int node = -1;
+        if (fscanf(f, "%d", &node) == 1)
+            *numa_node = node;
+        fclose(f);
+    }
+    return RF_OK;
+}
+
 int rf_create(int device, rf_ctx **out)
 {
     RF_REQUIRE(out != nullptr, "rf_create: out is NULL");
@@ -1294,6 +1315,8 @@ int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs)
         ctx->env_steps += 1;
         ctx->env_scene_len = k > 0 ? k : ctx->env_host.n;
         ctx->env_last_partial = k > 0;
+    } else {
+        ctx->env_needs_reset = true; // the second half failed part way: only a reset makes the environment usable again
     }
     return rc;
 }
@@ -1330,11 +1353,12 @@ int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *hos
     const int k = ctx->env_pending;
     RF_REQUIRE(k == 0 || (host_pool != nullptr && host_focus != nullptr),
                "rf_env_step_end_given: %d environments ended but host_pool / host_focus is NULL", k);
+    RF_REQUIRE(k <= ctx->focus_cap, "rf_env_step_end_given: focus buffer smaller than %d", k); // (before anything changes)
     RF_HIP(hipSetDevice(ctx->device));
     ctx->env_pending = -1;
+    ctx->env_needs_reset = true; // until the second half has finished (a HIP failure below returns early)
     const int n = ctx->env_host.n;
     if (k > 0) {
-        RF_REQUIRE(k <= ctx->focus_cap, "rf_env_step_end_given: focus buffer smaller than %d", k);
         RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
         // the focus values were measured elsewhere: they take the place launch_focus would have filled
         RF_HIP(hipMemcpyAsync(ctx->d_var, host_focus, (size_t)k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1346,6 +1370,7 @@ int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *hos
     }
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_needs_reset = false;
     ctx->env_steps += 1;
     return RF_OK;
 }

@@ -202,7 +202,10 @@ class _HostGlue:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
 
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
-                 samples_per_pixel=100, seed=None, device=None, first_state_index=0, _diverging_only=False):
+                 samples_per_pixel=100, seed=None, device=None, first_state_index=0, host_frames=False,
+                 _diverging_only=False):
+        """host_frames=True: the literal drop-in route (FastRenderer(host_frames=True): frames come back to the
+        host every render and vision.focus_values uploads them again), identical results."""
         super().__init__()
         ends = (5.0, 10.0)
         target_radius = 0.25
@@ -214,7 +217,7 @@ class _HostGlue:
         self.num_envs = num_envs
 
         self._renderer = render.FastRenderer(samples_per_pixel=samples_per_pixel, device=device,
-                                             first_state_index=first_state_index)
+                                             first_state_index=first_state_index, host_frames=host_frames)
         self._ender = _Ender(num_envs, None if _diverging_only else max_episode_steps, target_radius / 2, 3)
         self._initializer = _Initializer(ends, seed)
         self._focus_observer = state_observer.FocusObserver(num_envs, TARGET, FOCUS, ends, self._renderer,
@@ -555,11 +558,19 @@ class _ShardSet:
         self._env = env
 
     def render(self, frame_height):
-        return np.concatenate(self._env._each(lambda shard: np.asarray(shard.render(frame_height))))
+        # After a step in which k > 0 environments ended, one device holds the k compacted rows of the auto-reset
+        # (rf_env_scene_len): here those are the shards that had resets, in shard order -- global index order, the
+        # compacted order.  A shard without resets that step still holds its full set and contributes nothing then.
+        ended = self._env._last_ended
+        partial = ended is not None and sum(ended) > 0
+        chosen = [g for g in range(len(self._env._shards)) if not partial or ended[g] > 0]
+        futures = [self._env._threads[g].submit(lambda shard=self._env._shards[g]: np.asarray(shard.render(frame_height)))
+                   for g in chosen]
+        return np.concatenate([f.result() for f in futures])
 
     def status(self, index):
         g, local = self._env._locate(index)
-        return self._env._shards[g].status(local)
+        return self._env._threads[g].submit(self._env._shards[g].status, local).result()
 
 
 class ShardedVectorDiscreteSteps(_VectorEnvBase):
@@ -591,12 +602,13 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
     render_mode="rgb_array": HistoryVisualizer over the shards (each shard's 600 px render advances /
     re-seeds that shard's RNG states as the reference's single renderer would for its range; the
     exact mode does not extend to visualised runs).  `devices` may name a device more than once
-    (several contexts on one GPU: tests, rehearsals)."""
+    (several contexts on one GPU: tests, rehearsals).  numa_pin: every shard thread restricts itself
+    to the CPUs of its GPU's NUMA node (`placements` says where each shard ended up)."""
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 4}
 
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, devices=None, frame_height=300,
-                 samples_per_pixel=100, seed=None, first_state_index=0, exact=False):
+                 samples_per_pixel=100, seed=None, first_state_index=0, exact=False, numa_pin=True):
         import concurrent.futures
         import copy
 
@@ -604,8 +616,12 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
 
         super().__init__()
         assert render_mode is None or render_mode in self.metadata["render_modes"]
+        # (one array of RNG states aliased by 300 px and 600 px renders cannot be reproduced across devices, and the
+        # exact mode's row renders replace the scene sets the visualiser would draw)
+        assert not (exact and render_mode), "exact=True does not extend to visualised runs (render_mode)"
         self.render_mode = render_mode
         self.exact = bool(exact)
+        self._last_ended = None  # environments that ended in the last step, per shard (None: after a reset)
         self._copy = copy
         if devices is None:
             devices = list(range(_native.device_count()))
@@ -623,16 +639,25 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         pixels = frame_height * frame_height
         self._shards = []
         try:
-            futures = [thread.submit(_DeviceShard, count, max_episode_steps, frame_height, samples_per_pixel,
-                                     device, first_state_index + first * pixels)
+            def make_shard(count, device, first):
+                # (in the shard's own thread, before its context exists: the thread that will drive the GPU -- and
+                # first-touch its pinned staging buffers -- runs on the CPUs of that GPU's NUMA node)
+                placement = _native.device_info(device)
+                placement["cpus"] = _native.pin_to_numa_node(placement["numa_node"]) if numa_pin else None
+                shard = _DeviceShard(count, max_episode_steps, frame_height, samples_per_pixel, device,
+                                     first_state_index + first * pixels)
+                shard.placement = placement
+                return shard
+
+            futures = [thread.submit(make_shard, count, device, first)
                        for thread, device, (first, count) in zip(self._threads, devices, self._ranges)]
             for future in futures:
                 try:
                     self._shards.append(future.result())
                 except Exception:
-                    for other in futures:
-                        try:
-                            other.result().ctx.close()
+                    for thread, other in zip(self._threads, futures):
+                        try:  # (a context is only ever touched from its own thread)
+                            thread.submit(other.result().ctx.close).result()
                         except Exception:
                             pass
                     raise
@@ -648,6 +673,12 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
             self._visualizer = episode_visualizer.HistoryVisualizer(
                 num_envs, TARGET, FOCUS, 1, both, self._limits, ender=both, target_radius=_DeviceShard.TARGET_RADIUS)
 
+    @property
+    def placements(self):
+        """Per shard: {"device", "pci_bus_id", "numa_node", "cpus"} -- which physical GPU the shard's context is on
+        and the CPUs its host thread was restricted to (None: not pinned)."""
+        return [dict(shard.placement) for shard in self._shards]
+
     def _submit(self, function, *per_shard):
         return [thread.submit(function, shard, *(a[g] for a in per_shard))
                 for g, (thread, shard) in enumerate(zip(self._threads, self._shards))]
@@ -655,6 +686,20 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
     def _each(self, function, *per_shard):
         """function(shard, *args_g) on every shard's own thread; results in shard order."""
         return [f.result() for f in self._submit(function, *per_shard)]
+
+    @staticmethod
+    def _results(futures):
+        """Every future's result; all of them are waited for before the first error is raised (no shard is left
+        running behind an exception)."""
+        results, errors = [], []
+        for future in futures:
+            try:
+                results.append(future.result())
+            except Exception as error:  # noqa: BLE001 -- re-raised below
+                errors.append(error)
+        if errors:
+            raise errors[0]
+        return results
 
     def _slices(self, array):
         return [array[first:first + count] for first, count in self._ranges]
@@ -675,6 +720,7 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         initial = (self._initializer.initialize(self.num_envs) if state is None
                    else np.array(state, dtype=np.float32).reshape(self.num_envs, 2))
         observations = np.concatenate(self._each(lambda shard, rows: shard.ctx.env_reset(rows), self._slices(initial)))
+        self._last_ended = None
         if self._visualizer is not None:
             self._visualizer.reset(initial, observations)
         return observations, {}
@@ -711,19 +757,32 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         starts = np.concatenate([[0], np.cumsum(ended)]).astype(int)
         total = int(starts[-1])
         rows = [pool[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
-        if self.exact and total:
-            # compacted row r is rendered where environment slot r's RNG states live
-            spans = [(first, min(first + count, total)) for first, count in self._ranges]
-            renders = [thread.submit(shard.ctx.env_render_states, pool[lo:hi])
-                       for thread, shard, (lo, hi) in zip(self._threads, self._shards, spans) if lo < hi]
-            focus = np.concatenate([r.result() for r in renders])
-            assert len(focus) == total
-            values = [focus[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
-            observations = self._each(lambda shard, r, v: shard.ctx.env_step_end_given(r, v), rows, values)
-        elif self.exact:
-            observations = self._each(lambda shard, r: shard.ctx.env_step_end_given(r, np.zeros(0)), rows)
-        else:
-            observations = self._each(lambda shard, r: shard.ctx.env_step_end(r), rows)
+        try:
+            if self.exact and total:
+                # compacted row r is rendered where environment slot r's RNG states live
+                spans = [(first, min(first + count, total)) for first, count in self._ranges]
+                renders = [thread.submit(shard.ctx.env_render_states, pool[lo:hi])
+                           for thread, shard, (lo, hi) in zip(self._threads, self._shards, spans) if lo < hi]
+                focus = np.concatenate(self._results(renders))
+                assert len(focus) == total
+                values = [focus[starts[g]:starts[g] + ended[g]] for g in range(len(self._shards))]
+                observations = self._results(self._submit(lambda shard, r, v: shard.ctx.env_step_end_given(r, v),
+                                                          rows, values))
+            elif self.exact:
+                observations = self._results(self._submit(lambda shard, r: shard.ctx.env_step_end_given(r, np.zeros(0)),
+                                                          rows))
+            else:
+                observations = self._results(self._submit(lambda shard, r: shard.ctx.env_step_end(r), rows))
+        except Exception:
+            # some shard failed in the second half: the others must not keep a half-finished step (those that had
+            # finished theirs refuse the abort, which is fine) -- every shard then insists on a reset or was done
+            for abort in [thread.submit(shard.ctx.env_step_abort) for thread, shard in zip(self._threads, self._shards)]:
+                try:
+                    abort.result()
+                except Exception:  # noqa: BLE001 -- no open step on that shard
+                    pass
+            raise
+        self._last_ended = ended
         if total:
             self._initializer.initialize(total)  # consume exactly the rows that were used
         observations = np.concatenate(observations)

@@ -73,16 +73,20 @@ class FastRenderer:
     """Produces images of focus scenes (render.py:122-145)."""
 
     def __init__(self, block_shape=(1, 16, 16), samples_per_pixel=100, r_size=20, device=None,
-                 first_state_index=0):
+                 first_state_index=0, host_frames=False):
         """block_shape is accepted for signature parity; the gfx950 kernel fixes its own
         launch geometry (256-thread blocks, lanes along x).  `device` / `first_state_index`
-        are extensions for one-process-per-GPU sharding (default: LOCAL_RANK, 0)."""
+        are extensions for one-process-per-GPU sharding (default: LOCAL_RANK, 0).
+        host_frames=True is the literal drop-in (INTEGRATION.md's stub): render() returns the
+        numpy array itself -- rf_render with host_out, one device-to-host copy of every frame per
+        call, as the reference's copy_to_host (render.py:188) -- instead of a DeviceFrames handle."""
         self._block_shape = cutil.check_block_shape(block_shape)
         self._samples_per_pixel = samples_per_pixel
         self._cameras = camera.FastCameras()
         self._worlds = world.FastWorlds(r_size=r_size)
         self._ctx = _native.Context(device)
         self._first_state_index = int(first_state_index)
+        self._host_frames = bool(host_frames)
         self._n_states = 0  # render.py:145 _random_states = None
         self._uploaded = (-1, -1)
         self._generation = 0
@@ -128,6 +132,9 @@ class FastRenderer:
         last = self._last_frames() if self._last_frames is not None else None
         if last is not None:
             last._detach()
+        if self._host_frames:
+            self._generation += 1
+            return self._ctx.render(n, frame_height, frame_height, self._samples_per_pixel, to_host=True)
         self._ctx.render(n, frame_height, frame_height, self._samples_per_pixel)
         self._generation += 1
         frames = DeviceFrames(self, grid_shape + (3,), self._generation)

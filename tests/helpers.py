@@ -15,16 +15,22 @@ def on_gpu_box():
     return os.path.exists("/dev/kfd")
 
 
-def verify_srchash(library):
+def verify_srchash(library, extra=None):
     """The Makefiles write <library>.srchash (sha256 of every prerequisite, paths relative to the
-    Makefile's directory) when they link: the library was built from the sources next to it iff every
-    recorded hash still matches."""
+    Makefile's directory; csrc/Makefile adds an "extra: <-D options>" line) when they link: the library
+    was built from the sources next to it iff every recorded hash still matches.  `extra`: the -D options
+    the library has to have been built with ("" for the product: a build with timing-experiment or test
+    options must never pass for it)."""
     stamp = library + ".srchash"
     assert os.path.exists(library), f"{library} is missing: run __graft_entry__.build() where the sources are edited"
     assert os.path.exists(stamp), f"{stamp} is missing: {library} was not built by its Makefile"
     # the stamp of a library built with OUT=<elsewhere> still names paths relative to the Makefile that built it
     bases = [os.path.dirname(library), os.path.join(ROOT, "reinfocus_amd", "csrc")]
-    lines = [line.split() for line in open(stamp).read().splitlines() if line.strip()]
+    text = [line for line in open(stamp).read().splitlines() if line.strip()]
+    recorded_extra = [line[len("extra:"):].strip() for line in text if line.startswith("extra:")]
+    if extra is not None:
+        assert recorded_extra == [extra], f"{library} was built with options {recorded_extra}, wanted [{extra!r}]"
+    lines = [line.split() for line in text if not line.startswith("extra:")]
     assert lines, f"{stamp} is empty"
     for digest, path in lines:
         source = next((os.path.join(b, path) for b in bases if os.path.exists(os.path.join(b, path))), None)

@@ -63,6 +63,29 @@ def test_bench_launches_its_own_ranks():
     assert "one process per GPU" in line["config"]["sharding"]
 
 
+def test_the_line_names_one_distinct_gpu_per_rank():
+    """Every rank reports which physical GPU it used (PCI bus id, NUMA node) and the CPUs it ran on; rank 0 prints
+    the table and the launch fails when two ranks name the same GPU (here from a fake table: no GPU on this host)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["REINFOCUS_BENCH_FAKE_DEVICES"] = "0000:05:00.0@0,0000:c5:00.0@1"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--plumbing-test", "--steps", "2", "--warmup", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert [(d["rank"], d["device"], d["pci_bus_id"], d["numa_node"]) for d in line["devices"]] == \
+        [(0, 0, "0000:05:00.0", 0), (1, 1, "0000:c5:00.0", 1)]
+    assert all(d["cpus"] and d["host"] for d in line["devices"])
+    # two ranks on one GPU: not a 2-GPU measurement
+    env["REINFOCUS_BENCH_FAKE_DEVICES"] = "0000:05:00.0@0"
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "both ran on the GPU at 0000:05:00.0" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # ... unless the run says it is a rehearsal on one device
+    env["REINFOCUS_BENCH_DEVICE"] = "0"
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+
+
 def test_a_failing_rank_fails_the_launch():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["REINFOCUS_BENCH_FAIL_RANK"] = "1"

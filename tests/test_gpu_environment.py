@@ -144,6 +144,46 @@ def test_device_resident_step_equals_host_harness(n, height, spp, steps, branch,
     dev.close()
 
 
+def test_literal_drop_in_route_equals_the_resident_one():
+    """INTEGRATION.md's literal stub -- rf_render(host_out) -> numpy array -> rf_upload_frames + rf_focus on a scratch
+    context (FastRenderer(host_frames=True), what `bench.py --env literal` measures) -- against frames that stay in
+    HBM: same frames, same observations, rewards, flags and states through auto-resets."""
+    from reinfocus_amd.environments import harness
+    from reinfocus_amd.graphics import render
+
+    kw = dict(num_envs=48, frame_height=24, samples_per_pixel=3, seed=7, device=0)
+    resident = harness.VectorDiscreteSteps(**kw)
+    literal = harness.VectorDiscreteSteps(host_frames=True, **kw)
+    o_r, _ = resident.reset()
+    o_l, _ = literal.reset()
+    assert np.array_equal(o_r, o_l)
+    rng = np.random.default_rng(3)
+    resets = 0
+    for _ in range(25):
+        actions = rng.integers(0, 13, kw["num_envs"])
+        a, b = resident.step(actions), literal.step(actions)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(resident._state, literal._state)
+        resets += int(a[3].sum())
+    assert resets > 0
+    frames = literal._renderer.render(24)
+    assert isinstance(frames, np.ndarray) and frames.dtype == np.uint8 and frames.shape[1:] == (24, 24, 3)
+    assert isinstance(resident._renderer.render(24), render.DeviceFrames)
+    resident.close()
+    literal.close()
+
+
+def test_device_info_names_the_gpu():
+    from reinfocus_amd import _native
+
+    info = _native.device_info(0)
+    bus = info["pci_bus_id"]
+    assert info["device"] == 0 and len(bus.split(":")) == 3 and bus == bus.lower() and isinstance(info["numa_node"], int)
+    with pytest.raises(AssertionError):
+        _native.device_info(_native.device_count())
+
+
 def test_env_step_graph_survives_other_calls_on_the_context():
     """Small configurations replay rf_env_step as one hipGraph from their second step on.  The
     graph holds device pointers and kernel arguments by value, so every call that may reallocate a

@@ -32,6 +32,8 @@ class FakeContext:
         self.rendered_rows = 0
         self.aborted = False
         self.fail_next_begin = False
+        self.fail_next_end = False
+        self.last_k = None  # rows of the scene set uploaded last: k after a partial auto-reset, else all (rf_env_scene_len)
 
     def _obs(self):
         return np.column_stack([self.state, self.steps, self.steps * 0]).astype(np.float32)
@@ -39,6 +41,7 @@ class FakeContext:
     def env_reset(self, states):
         self.state = np.array(states, dtype=np.float32).reshape(self.n, 2)
         self.steps[:] = 0
+        self.last_k = None
         return self._obs()
 
     def env_step_begin(self, actions):
@@ -53,9 +56,13 @@ class FakeContext:
         return self.state.sum(axis=1).astype(np.float64), truncated.copy(), int(truncated.sum())
 
     def env_step_end(self, rows):
+        if self.fail_next_end:
+            self.fail_next_end = False
+            raise RuntimeError("injected failure in the second half")
         truncated, self.pending = self.pending, None
         rows = np.asarray(rows, dtype=np.float32).reshape(-1, 2)
         assert len(rows) == truncated.sum()
+        self.last_k = int(truncated.sum()) or None
         self.state[truncated] = rows
         self.steps[truncated] = 0
         return self._obs()
@@ -93,7 +100,10 @@ def fake_shards(monkeypatch):
     from reinfocus_amd import _native
     from reinfocus_amd.environments import harness
 
-    made = []
+    class Made(list):
+        pins = None
+
+    made = Made()
 
     class FakeShard:
         ENDS, TARGET_RADIUS, MAX_MOVE = harness._DeviceShard.ENDS, 0.25, 5.0
@@ -106,15 +116,68 @@ def fake_shards(monkeypatch):
             self.ctx = FakeContext(num_envs, self.first_env)
             made.append(self)
 
-        def render(self, frame_height):  # what HistoryVisualizer asks of a renderer
-            return np.full((self.num_envs, frame_height, frame_height, 3), self.first_env, dtype=np.uint8)
+        def render(self, frame_height):  # what HistoryVisualizer asks of a renderer: the scene set uploaded last
+            rows = self.ctx.last_k or self.num_envs
+            return np.full((rows, frame_height, frame_height, 3), self.first_env, dtype=np.uint8)
 
         def status(self, index):  # ... and of an ender
             return f"env {self.first_env + index}"
 
     monkeypatch.setattr(harness, "_DeviceShard", FakeShard)
     monkeypatch.setattr(_native, "device_count", lambda: 4)
+    # a host with two NUMA nodes: devices 0, 1 on node 0 (CPUs 0-3), devices 2, 3 on node 1 (CPUs 4-7)
+    monkeypatch.setattr(_native, "device_info",
+                        lambda d: {"device": d, "pci_bus_id": f"0000:{0x10 + d:02x}:00.0", "numa_node": d // 2})
+    pins = []
+
+    def fake_pin(node, whole_process=False, sysfs=None):
+        import threading
+
+        pins.append((threading.current_thread().name, node))
+        return list(range(4 * node, 4 * node + 4))
+
+    monkeypatch.setattr(_native, "pin_to_numa_node", fake_pin)
+    made.pins = pins
     return made
+
+
+def test_shard_threads_pin_themselves_to_their_gpus_numa_node(fake_shards):
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=8, devices=[0, 1, 2, 3], frame_height=16, samples_per_pixel=1, seed=1)
+    assert [p["pci_bus_id"] for p in env.placements] == ["0000:10:00.0", "0000:11:00.0", "0000:12:00.0", "0000:13:00.0"]
+    assert [p["numa_node"] for p in env.placements] == [0, 0, 1, 1]
+    assert [p["cpus"] for p in env.placements] == [[0, 1, 2, 3], [0, 1, 2, 3], [4, 5, 6, 7], [4, 5, 6, 7]]
+    # every shard pinned its OWN thread (the one its context is driven from), not the caller's
+    assert sorted(fake_shards.pins) == [(f"reinfocus-shard{g}_0", g // 2) for g in range(4)]
+    env.close()
+    del fake_shards.pins[:]
+    env = harness.ShardedVectorDiscreteSteps(num_envs=4, devices=[0, 3], frame_height=16, samples_per_pixel=1, seed=1,
+                                             numa_pin=False)
+    assert fake_shards.pins == [] and [p["cpus"] for p in env.placements] == [None, None]
+    env.close()
+
+
+def test_numa_helpers(tmp_path):
+    from reinfocus_amd import _native
+
+    (tmp_path / "node1").mkdir()
+    (tmp_path / "node1" / "cpulist").write_text("2-3,9,64-66\n")
+    assert _native.numa_cpus(1, sysfs=str(tmp_path)) == {2, 3, 9, 64, 65, 66}
+    assert _native.numa_cpus(5, sysfs=str(tmp_path)) == set()
+    assert _native.pin_to_numa_node(-1) is None and _native.pin_to_numa_node(None) is None
+    # a node none of whose CPUs this process may use changes nothing
+    (tmp_path / "node2").mkdir()
+    (tmp_path / "node2" / "cpulist").write_text("100000-100001\n")
+    assert _native.pin_to_numa_node(2, sysfs=str(tmp_path)) is None
+    # a node that contains this thread's current CPUs: pinned to the intersection, and harmless
+    import os
+
+    now = sorted(os.sched_getaffinity(0))
+    (tmp_path / "node3").mkdir()
+    (tmp_path / "node3" / "cpulist").write_text(",".join(str(c) for c in now) + ",100000\n")
+    assert _native.pin_to_numa_node(3, sysfs=str(tmp_path)) == now
+    assert sorted(os.sched_getaffinity(0)) == now
 
 
 def test_split_environments():
@@ -220,6 +283,47 @@ def test_a_failing_shard_does_not_leave_the_others_half_way(fake_shards):
     env.reset()
     env.step(np.zeros(9, dtype=np.int64))  # usable again after a reset
     env.close()
+
+
+def test_a_failure_in_the_second_half_leaves_no_open_step(fake_shards):
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=9, devices=[0, 1, 2], frame_height=8, samples_per_pixel=1, seed=1)
+    env.reset()
+    shards = sorted(fake_shards, key=lambda s: s.first_env)
+    shards[1].ctx.fail_next_end = True
+    with pytest.raises(RuntimeError, match="second half"):
+        env.step(np.zeros(9, dtype=np.int64))
+    # the shard that failed still had its step open and dropped it; the others had finished theirs
+    assert shards[1].ctx.aborted and all(s.ctx.pending is None for s in shards)
+    env.reset()
+    env.step(np.zeros(9, dtype=np.int64))
+    env.close()
+
+
+def test_renders_after_a_partial_reset_are_the_compacted_rows(fake_shards):
+    """After a step in which k environments ended one device holds the k compacted rows (rf_env_scene_len); sharded,
+    those are the shards that had resets, in shard order -- a shard without resets contributes nothing."""
+    from reinfocus_amd.environments import harness
+
+    env = harness.ShardedVectorDiscreteSteps(num_envs=6, devices=[0, 1], render_mode="rgb_array", frame_height=8,
+                                             samples_per_pixel=1, seed=0)
+    env.reset()
+    assert env.render_frames().shape[0] == 6  # after a reset: every environment
+    shards = sorted(fake_shards, key=lambda s: s.first_env)
+    shards[0].ctx.period[:] = 100  # only shard 1's environments end in the next steps
+    shards[1].ctx.period[:] = [1, 100, 1]
+    *_, truncated, _ = env.step(np.zeros(6, dtype=np.int64))
+    assert list(truncated) == [False, False, False, True, False, True]
+    frames = env.render_frames()
+    assert frames.shape[0] == 2 and set(frames[:, 0, 0, 0]) == {3}  # two compacted rows, both drawn by shard 1
+    shards[1].ctx.period[:] = 100
+    env.step(np.zeros(6, dtype=np.int64))  # nobody ended: the full sets again
+    assert env.render_frames().shape[0] == 6
+    env.close()
+    with pytest.raises(AssertionError, match="exact"):
+        harness.ShardedVectorDiscreteSteps(num_envs=4, devices=[0, 1], render_mode="rgb_array", exact=True, frame_height=8,
+                                           samples_per_pixel=1)
 
 
 def test_every_shard_has_its_own_thread(fake_shards):
