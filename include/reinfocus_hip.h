@@ -125,11 +125,6 @@ const char *rf_render_kernel_name(rf_ctx *ctx);
  * it, so that per-pixel figures count the pixels really rendered (not waves x pixels per wave). */
 unsigned long long rf_pixels_rendered(void);
 
-/* Pixels the last launch of the ctx's last rf_render_general left to its fix-up kernel (the pixels with a
- * checker colour float32 could not decide, rendered again by the literal float64 code; csrc/rf_general_coop.h);
- * 0 before the first call.  No reference counterpart (tools/bench_general.py and the tests report the share). */
-unsigned rf_general_redo_pixels(rf_ctx *ctx);
-
 /* Blocks until everything enqueued on the ctx's stream has finished. */
 int rf_synchronize(rf_ctx *ctx);
 

@@ -193,7 +193,7 @@ __device__ __forceinline__ void coop_workers(CoopLds2 &lds, int parity, int *cnt
         *cnt = 0;
 }
 
-// One cooperative call for the stragglers (lane masks `need`) of the NS (= kSets here) pixel sets: park, finish on packed waves,
+// One cooperative call for the stragglers (lane masks `need`) of the kSets pixel sets: park, finish on packed waves,
 // collect.  The packed list holds kCoopCap entries; stragglers that do not fit finish their loop in their own wave.
 // Returns the number of stragglers the block had (block-uniform).
 // WAVE_SLOTS: the stragglers' list slots by ONE LDS atomic per wave and call -- the masks are the ballots, the ranks
@@ -204,22 +204,18 @@ __device__ __forceinline__ void coop_workers(CoopLds2 &lds, int parity, int *cnt
 // atomic optimizer would turn the per-straggler form into exactly the ballot form.)
 // FENCED: the caller's disc phase has no block barrier (see SYNCHRONISATION above): `cnt` alternates with the sample
 // and the call ends with B4.
-// vote (the general renderer's bounce loop, rf_general_coop.h): a block-wide OR rides on B1 -- every wave with
-// `vote_yes` adds one to the never-reset LDS word *vote before the barrier, everybody reads it after (*vote_seen):
-// it has moved since the caller's previous call with this word iff some wave voted.
-template <int DIM, bool WAVE_SLOTS, bool FENCED, int NS = kSets>
-__device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt, const lanemask (&need)[NS],
-                                             Rng (&g)[NS], uint32_t (&w)[NS][6], int tid, int *vote = nullptr,
-                                             bool vote_yes = false, int *vote_seen = nullptr)
+template <int DIM, bool WAVE_SLOTS, bool FENCED>
+__device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt, const lanemask (&need)[kSets],
+                                             Rng (&g)[kSets], uint32_t (&w)[kSets][6], int tid)
 {
     asm volatile("" : "+v"(tid)); // keeps the LDS addresses derived from it out of long-lived registers
     uint4 *const state = lds.state[parity];
-    int slot[NS];
-    lanemask parked[NS];
+    int slot[kSets];
+    lanemask parked[kSets];
     if (WAVE_SLOTS) {
-        int pop[NS], all = 0;
+        int pop[kSets], all = 0;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
+        for (int j = 0; j < kSets; ++j) {
             pop[j] = (int)__builtin_popcountll(need[j]);
             all += pop[j];
         }
@@ -230,7 +226,7 @@ __device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt
             base = __builtin_amdgcn_readfirstlane(base);
         }
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
+        for (int j = 0; j < kSets; ++j) {
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need[j] >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((unsigned)need[j], 0));
             slot[j] = base + rank * 16;
@@ -238,7 +234,7 @@ __device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
+        for (int j = 0; j < kSets; ++j) {
             // (all sets' atomics are issued before the first result is waited for)
             slot[j] = (int)any_u32();
             if (lane_in(need[j]))
@@ -246,7 +242,7 @@ __device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt
         }
     }
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
+    for (int j = 0; j < kSets; ++j) {
         parked[j] = need[j] & lanes_where(slot[j] < kCoopCap * 16); // (a ballot of one compare is that compare)
         if (lane_in(parked[j]))
             *entry16(state, slot[j]) = make_uint4(g[j].a_lo, g[j].a_hi, g[j].b_lo, g[j].b_hi);
@@ -260,18 +256,14 @@ __device__ __forceinline__ int coop_finish2m(CoopLds2 &lds, int parity, int *cnt
             }
         }
     }
-    if (vote != nullptr && vote_yes && (tid & 63) == 0)
-        atomicAdd(vote, 1);
     __syncthreads(); // B1
-    if (vote != nullptr)
-        *vote_seen = __builtin_amdgcn_readfirstlane(*vote);
     const int stragglers = __builtin_amdgcn_readfirstlane(*cnt) >> 4; // (a scalar: the branches below are s_cmp)
     const int total = min(stragglers, kCoopCap);
     if (total == 0) // block-uniform
         return 0;
     coop_workers<DIM>(lds, parity, cnt, total, tid);
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
+    for (int j = 0; j < kSets; ++j) {
         if (lane_in(parked[j])) {
             uint4 ps = *entry16(state, slot[j]);
             // (opaque: or the first draw's 64-bit sum is fed by a second, 8-byte read of the same entry)
