@@ -4,6 +4,7 @@
 // (AXIS / POW2 / integer uniform / checker table) with the oracle before any GPU
 // time is spent.  Never loaded by the product package.
 #include <math.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "../../reinfocus_amd/csrc/rf_math.h"
@@ -353,6 +354,59 @@ int hs_probe_uv_approx(const float *normals, float *uv, uint64_t n)
     for (uint64_t i = 0; i < n; ++i)
         probe::sphere_uv_fast(normals + 3 * i, uv + 2 * i);
     return 0;
+}
+
+// sphere.hit (sphere.py:40-103) as the reference writes it -- float64 roots for every ray with a non-negative
+// discriminant -- next to rf::sphere_hit, which decides the certain misses in float32 first: both on the same rays.
+// rec = p[3], n[3], t; returns the number of rays on which they differ (hit flag, or any bit of a hit's record).
+static bool sphere_hit_literal(const float *sp, const float o[3], const float d[3], float t_min, float t_max, float rec[7])
+{
+    const float oc[3] = {o[0] - sp[0], o[1] - sp[1], o[2] - sp[2]};
+    const float a = rf::dot3(d, d), b = rf::dot3(oc, d), c = rf::dot3(oc, oc) - sp[3] * sp[3];
+    const float disc = b * b - a * c;
+    if (disc < 0)
+        return false;
+    const double sqrtd = sqrt((double)disc);
+    double root = (-(double)b - sqrtd) / (double)a;
+    if (root < (double)t_min || (double)t_max < root) {
+        root = (-(double)b + sqrtd) / (double)a;
+        if (root < (double)t_min || (double)t_max < root)
+            return false;
+    }
+    const float inv_r = (float)(1.0 / (double)sp[3]);
+    for (int k = 0; k < 3; ++k) {
+        rec[k] = rf::add2(o[k], (float)((double)d[k] * root));
+        rec[3 + k] = (rec[k] - sp[k]) * inv_r;
+    }
+    rec[6] = (float)root;
+    return true;
+}
+
+long hs_check_sphere_hit(const float *spheres, const float *origins, const float *dirs, float t_min, float t_max, long n,
+                         long *hits, long *shortcuts)
+{
+    long bad = 0, n_hit = 0, n_short = 0;
+#pragma omp parallel for reduction(+ : bad, n_hit, n_short)
+    for (long i = 0; i < n; ++i) {
+        const float *sp = spheres + 4 * i, *o = origins + 3 * i, *d = dirs + 3 * i;
+        float want[7] = {0, 0, 0, 0, 0, 0, 0};
+        const bool hit = sphere_hit_literal(sp, o, d, t_min, t_max, want);
+        rf::HitRec r;
+        const bool got = rf::sphere_hit(sp, o, d, t_min, t_max, r);
+        const float have[7] = {r.p[0], r.p[1], r.p[2], r.n[0], r.n[1], r.n[2], r.t};
+        if (got != hit || (hit && memcmp(want, have, sizeof(want)) != 0))
+            ++bad;
+        n_hit += hit ? 1 : 0;
+        // (how often the float32 test is the one that answers: the same expression as in rf_general.h)
+        const float oc[3] = {o[0] - sp[0], o[1] - sp[1], o[2] - sp[2]};
+        const float a = rf::dot3(d, d), b = rf::dot3(oc, d), c = rf::dot3(oc, oc) - sp[3] * sp[3];
+        const float disc = b * b - a * c, reach = b + t_min * a;
+        if (!(disc < 0) && a > 0.0f && b > 0.0f && disc < (reach * reach) * 0.99999904632568359375f)
+            ++n_short;
+    }
+    *hits = n_hit;
+    *shortcuts = n_short;
+    return bad;
 }
 
 int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)

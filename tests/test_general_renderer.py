@@ -281,3 +281,49 @@ def test_sphere_checker_fast_path_equals_the_float64_expressions():
     hs.hs_probe_sphere_red(1, ptr(normals), ptr(fu), ptr(fv), ptr(reference), ctypes.c_uint64(n))
     assert np.array_equal(fast, reference)
     assert 0.4 < reference.mean() < 0.6
+
+
+def test_sphere_miss_shortcut_equals_the_float64_roots(oracle):
+    """rf_general.h sphere_hit answers the certain misses -- a ray pointing away from the centre whose far root is
+    below t_min: every ray that has just scattered off the sphere -- from float32 (disc < (b + t_min a)^2 with a
+    margin) before any float64 is computed.  Against the reference's float64 expressions (sphere.py:40-103) on rays
+    of every kind: leaving the surface at every angle down to grazing, starting just inside / outside it, aimed at
+    the sphere from afar, with far roots on both sides of t_min and next to it; hit flags and every bit of the hit
+    records must agree, and the shortcut must be what answers most of the leaving rays."""
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    hs.hs_check_sphere_hit.restype = ctypes.c_long
+    rng = np.random.default_rng(11)
+    n = 3_000_000
+    centre = rng.uniform(-5, 5, (n, 3))
+    radius = rng.uniform(0.1, 8, n)
+    unit = rng.normal(size=(n, 3))
+    unit /= np.linalg.norm(unit, axis=1, keepdims=True)
+    kind = rng.integers(0, 4, n)
+    # where the ray starts: on the surface (float32 rounding puts it a hair inside or outside), a little off it, or far away
+    offset = np.select([kind == 0, kind == 1, kind == 2], [1.0, 1.0 + rng.choice([-1, 1], n) * 10.0 ** rng.uniform(-7, -2, n),
+                                                            1.0 + 10.0 ** rng.uniform(-4, 0, n)], rng.uniform(1.5, 6, n))
+    origin = centre + unit * (radius * offset)[:, None]
+    # direction: the normal plus a vector in / near the unit ball (a scattered ray), or aimed at / past the sphere
+    wobble = rng.normal(size=(n, 3))
+    wobble *= (rng.uniform(0, 1.05, n) ** (1 / 3) / np.linalg.norm(wobble, axis=1))[:, None]
+    aimed = (centre + rng.normal(size=(n, 3)) * radius[:, None] * rng.uniform(0, 1.5, n)[:, None]) - origin
+    direction = np.where((kind == 3)[:, None], aimed, unit + wobble)
+    direction[: n // 100] *= 1e-4  # tiny and huge directions: the roots scale, the t_min test does not
+    direction[n // 100: n // 50] *= 1e4
+    spheres = np.ascontiguousarray(np.column_stack([centre, radius]).astype(np.float32))
+    origin = np.ascontiguousarray(origin.astype(np.float32))
+    direction = np.ascontiguousarray(direction.astype(np.float32))
+    hits, shortcuts = ctypes.c_long(0), ctypes.c_long(0)
+    for t_min, t_max in ((0.001, 1000000.0), (0.001, 3.0), (0.0, 100.0)):
+        bad = hs.hs_check_sphere_hit(ptr(spheres), ptr(origin), ptr(direction), ctypes.c_float(t_min), ctypes.c_float(t_max),
+                                     ctypes.c_long(n), ctypes.byref(hits), ctypes.byref(shortcuts))
+        assert bad == 0, (t_min, t_max, bad)
+        assert n // 10 < hits.value < n and shortcuts.value > n // 4  # both kinds of answer are exercised
+    # ... and the literal form the check compares with is the oracle's (a sample through the Python binding)
+    for i in range(0, n, n // 400):
+        want_hit, want = oracle.sphere_hit(list(spheres[i]) + [4, 8], tuple(origin[i]), tuple(direction[i]), 0.001, 1000000.0)
+        from reinfocus_amd.graphics import shape  # noqa: F401  (layout of the record: p, n, t, uv, ...)
+        got = hs.hs_check_sphere_hit(ptr(spheres[i:i + 1]), ptr(origin[i:i + 1]), ptr(direction[i:i + 1]), ctypes.c_float(0.001),
+                                     ctypes.c_float(1000000.0), ctypes.c_long(1), ctypes.byref(hits), ctypes.byref(shortcuts))
+        assert got == 0 and bool(hits.value) == bool(want_hit)
