@@ -601,7 +601,11 @@ def main(argv=None):
         pinned = os.environ.get("REINFOCUS_BENCH_DEVICE")
         if _native.device_count() < (args.gpus if args.sharded_env and pinned is None else 1):
             raise SystemExit("bench.py needs a GPU per rank: reinfocus_amd has no CPU fallback")
-        device = int(pinned) if pinned is not None else ranks.local_rank
+        # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES per rank) leaves one visible
+        # device, index 0, whatever LOCAL_RANK says; the table of PCI bus ids below is what proves the ranks' GPUs distinct
+        visible = _native.device_count()
+        device = int(pinned) if pinned is not None else (ranks.local_rank if ranks.local_rank < visible
+                                                         else ranks.local_rank % visible)
         common = dict(num_envs=n_here, frame_height=frame, samples_per_pixel=spp, seed=ranks.rank)
         if args.sharded_env:
             devices = [int(pinned)] * args.gpus if pinned is not None else list(range(args.gpus))
