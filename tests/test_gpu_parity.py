@@ -428,6 +428,25 @@ def test_packed_list_overflow_finishes_in_place(ctx, oracle, tmp_path, h):
     assert np.array_equal(ctx.render(n, h, h, spp, to_host=True), want)
 
 
+@pytest.mark.parametrize("h", [128, 100, 256])
+def test_delayed_waves_change_nothing(oracle, tmp_path, h):
+    """The cooperative calls of render_kernel_coop2 are ordered against each other by barriers alone (rf_coop2.h,
+    SYNCHRONISATION): no wave may depend on another one being "about as fast".  tests/gpucheck builds the library with
+    RF_TEST_SKEW: one wave of every block, a different one from call to call, sleeps ~8 000 cycles before it reads the
+    counter after B1, before thread 0's resets and before the collect reads -- long enough for the other waves to be a
+    whole phase ahead wherever a barrier does not hold them.  Frames and RNG states must still equal the oracle's.
+    (The round-3 form of the call -- no barrier after the collect, one counter -- renders wrong pixels under the same
+    delays: profiles/r04_ab.txt section 7.)"""
+    so = helpers.built("tests/gpucheck", "libreinfocus_skew.so")
+    n, spp = 3, 6
+    d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
+    frames, final = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_HIP_LIB": so})
+    states = oracle.seed_states(n * h * h, 0)
+    want = oracle.render(d[0], d[1], h, h, spp, states)
+    assert np.array_equal(frames, want)
+    assert np.array_equal(final, states)
+
+
 @pytest.mark.parametrize("overrides", [{"REINFOCUS_RENDER_SETS": "1"}, {"REINFOCUS_RENDER_COOP": "0"}],
                          ids=["one-pixel-coop", "no-coop"])
 @pytest.mark.parametrize("h", [64, 50])
