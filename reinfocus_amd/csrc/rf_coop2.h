@@ -68,27 +68,6 @@ static_assert(kCoopCap >= 1 && kCoopCap <= kBlock2, "the packed list lives in Co
 #define RF_DISC_WAVE_SLOTS 64 // entries per wave of disc_tails_wave; tests/gpucheck builds an 8-entry form (in-place path)
 #endif
 constexpr int kDiscWaveSlots = RF_DISC_WAVE_SLOTS;
-// RF_TEST_SKEW (tests/gpucheck/libreinfocus_skew.so, tests/test_gpu_parity.py): one wave of every block -- a different
-// one from call to call -- sleeps ~8 000 cycles at each point where a cooperative call is ordered against the next
-// one by a barrier alone: before it reads the counter after B1, before thread 0's resets, before the collect reads.
-// With the ordering right the sleeps change nothing (frames and RNG states stay bit-identical to the oracle); the
-// round-3 form of the call -- no B4, one counter -- produces wrong frames under them (profiles/r04_ab.txt section 7).
-#ifndef RF_TEST_SKEW
-#define RF_TEST_SKEW 0
-#endif
-__device__ __forceinline__ void test_skew(int tid, int turn)
-{
-#if RF_TEST_SKEW
-    if (((tid >> 6) & 3) == (turn & 3)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_s_sleep(127); // 8 x 127 x 64 cycles
-    }
-#else
-    (void)tid;
-    (void)turn;
-#endif
-}
 static_assert(kDiscWaveSlots >= 1 && kDiscWaveSlots <= 64, "a wave's quarter of state[0]");
 
 constexpr int kCoopTrips2 = 1;      // in-wave sphere attempts before the cooperative call

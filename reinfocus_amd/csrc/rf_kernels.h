@@ -140,6 +140,29 @@ struct CoopLdsT {
 };
 using CoopLds = CoopLdsT<kBlock>;
 
+// RF_TEST_SKEW (tests/gpucheck/libreinfocus_skew.so, tests/test_gpu_parity.py; used by coop_finish here and by
+// rf_coop2.h): one wave of every block -- a different
+// one from call to call -- sleeps ~8 000 cycles at each point where a cooperative call is ordered against the next
+// one by a barrier alone: before it reads the counter after B1, before thread 0's resets, before the collect reads.
+// With the ordering right the sleeps change nothing (frames and RNG states stay bit-identical to the oracle); the
+// round-3 form of the call -- no B4, one counter -- produces wrong frames under them (profiles/r04_ab.txt section 7).
+#ifndef RF_TEST_SKEW
+#define RF_TEST_SKEW 0
+#endif
+__device__ __forceinline__ void test_skew(int tid, int turn)
+{
+#if RF_TEST_SKEW
+    if (((tid >> 6) & 3) == (turn & 3)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_s_sleep(127); // 8 x 127 x 64 cycles
+    }
+#else
+    (void)tid;
+    (void)turn;
+#endif
+}
+
 template <int DIM>
 __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need, Rng &g, uint32_t *w)
 {
@@ -158,6 +181,7 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
     if (need)
         state[slot] = make_uint4(g.a_lo, g.a_hi, g.b_lo, g.b_hi);
     __syncthreads();
+    test_skew(tid, parity + 1); // (a wave late with its read of the counter)
     const int total = lds.cnt[parity];
     if (total == 0) // block-uniform
         return;
@@ -178,8 +202,10 @@ __device__ __forceinline__ void coop_finish(CoopLds &lds, int parity, bool need,
             lds.words2[tid] = make_uint2(ww[4], ww[5]);
     }
     __syncthreads();
+    test_skew(tid, 0); // (wave 0, late with its reset)
     if (tid == 0)
         lds.cnt[parity] = 0;
+    test_skew(tid, total + 2); // (a wave late with its collect reads)
     if (need) {
         const uint4 ps = state[slot];
         g = Rng{ps.x, ps.y, ps.z, ps.w};

@@ -440,11 +440,13 @@ def test_delayed_waves_change_nothing(oracle, tmp_path, h):
     so = helpers.built("tests/gpucheck", "libreinfocus_skew.so")
     n, spp = 3, 6
     d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
-    frames, final = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_HIP_LIB": so})
     states = oracle.seed_states(n * h * h, 0)
-    want = oracle.render(d[0], d[1], h, h, spp, states)
-    assert np.array_equal(frames, want)
-    assert np.array_equal(final, states)
+    want = oracle.render(d[0], d[1], h, h, spp, states)  # (advances `states` in place)
+    # render_kernel_coop2 (three pixels per thread), and the one-pixel cooperative kernel behind REINFOCUS_RENDER_SETS=1
+    for overrides in ({}, {"REINFOCUS_RENDER_SETS": "1"}):
+        frames, final = _render_in_child(tmp_path, d, n, h, spp, dict(overrides, REINFOCUS_HIP_LIB=so))
+        assert np.array_equal(frames, want), overrides
+        assert np.array_equal(final, states), overrides
 
 
 @pytest.mark.parametrize("overrides", [{"REINFOCUS_RENDER_SETS": "1"}, {"REINFOCUS_RENDER_COOP": "0"}],
