@@ -49,6 +49,10 @@
 //       All four waves leave B3 together and C(k) is nine LDS reads, so they reach B4 together.
 //   disc_tails_wave works on the wave's own quarter of state[0], which after B3 nobody else reads (`other`
 //   is dead once round 2 is over) and which round 1 of the next call writes only after B1.
+//   Checked two ways: tests/test_sync_model.py writes this protocol down array by array and verifies, for every
+//   combination of call outcomes, that no two conflicting accesses of different waves share a barrier epoch (and that
+//   the round-3 form fails that check); tests/test_gpu_parity.py::test_delayed_waves_change_nothing runs a build
+//   whose waves are delayed at exactly these points (RF_TEST_SKEW, rf_kernels.h).
 #pragma once
 
 #include "rf_kernels.h"

@@ -1,0 +1,171 @@
+"""The ordering argument of render_kernel_coop2's cooperative calls (csrc/rf_coop2.h, "SYNCHRONISATION"), mechanised.
+
+A workgroup's waves execute the same sequence of barriers (every branch that contains one is block-uniform), so two
+accesses by different waves are ordered exactly when the waves have passed a different number of barriers before
+them.  This file writes down, per wave and sample, which LDS arrays every phase of the kernel reads, writes or
+updates atomically -- the protocol of rf_coop2.h, array by array -- and checks for every pair of phases that can meet
+in the same barrier epoch that they do not conflict.  It is a model next to the code, not the code: what it buys is
+that the argument in the header's comment is checked over every combination of call outcomes (no stragglers / one
+round / two rounds) instead of being read, and that it demonstrably finds the race of the round-3 form of the kernel
+(no barrier after the collect, one counter), which tests/test_gpu_parity.py::test_delayed_waves_change_nothing shows
+on the hardware."""
+
+import itertools
+
+import pytest
+
+R, W, A = "read", "write", "atomic"
+
+
+class Wave:
+    """Collects (epoch, phase, array, kind) of one wave; barrier() starts the next epoch."""
+
+    def __init__(self, index):
+        self.index = index
+        self.epoch = 0
+        self.events = []
+
+    def touch(self, phase, array, kind):
+        self.events.append((self.epoch, phase, array, kind))
+
+    def barrier(self):
+        self.epoch += 1
+
+
+# accesses of one phase that cannot collide with each other although several waves make them in one epoch: the slots
+# are dealt by an atomic (park, round-1 survivors), indexed by the worker's own thread (rounds), or the owner's own
+# (collect); atomics on one word are ordered by the LDS unit
+SELF_COMPATIBLE = {"park", "round1", "round2", "finish", "collect", "count"}
+
+
+def overlap(array_a, array_b):
+    """"state0/quarter2" is a wave's own quarter of state0: it overlaps state0 as a whole, not another quarter."""
+    whole_a, _, part_a = array_a.partition("/")
+    whole_b, _, part_b = array_b.partition("/")
+    return whole_a == whole_b and (not part_a or not part_b or part_a == part_b)
+
+
+def conflicts(a, b):
+    (_, phase_a, array_a, kind_a), (_, phase_b, array_b, kind_b) = a, b
+    if not overlap(array_a, array_b) or (kind_a == R and kind_b == R) or (kind_a == A and kind_b == A):
+        return False
+    if phase_a == phase_b and phase_a in SELF_COMPATIBLE:
+        return False
+    return True
+
+
+def races(waves):
+    found = []
+    for x, y in itertools.combinations(waves, 2):
+        for a in x.events:
+            for b in y.events:
+                if a[0] == b[0] and conflicts(a, b):
+                    found.append((x.index, a, y.index, b))
+    return found
+
+
+def cooperative_call(wave, dim, parity, counter, outcome, fenced, sample):
+    """coop_finish2m<DIM, *, FENCED>: `outcome` is block-uniform: "none" (no stragglers), "one" (the packed entries are
+    finished in one round), "two" (sphere calls with more than 64 entries: packing round + round 2)."""
+    state, other = f"state{parity}", f"state{parity ^ 1}"
+    wave.touch("park", counter, A)
+    wave.touch("park", state, W)
+    wave.barrier()  # B1
+    wave.touch("count", counter, R)
+    if outcome == "none":
+        return
+    if outcome == "two":
+        assert dim == 3
+        wave.touch("round1", state, R)
+        wave.touch("round1", state, W)
+        wave.touch("round1", "words4", W)
+        wave.touch("round1", "words2", W)
+        wave.touch("round1", "cnt2", A)
+        wave.touch("round1", other, W)
+        wave.touch("round1", "owner", W)
+        wave.barrier()  # B2
+        wave.touch("count", "cnt2", R)
+        wave.touch("round2", other, R)
+        wave.touch("round2", "owner", R)
+        wave.touch("round2", state, W)
+        wave.touch("round2", "words4", W)
+        wave.touch("round2", "words2", W)
+        wave.barrier()  # B3
+        if wave.index == 0:
+            wave.touch("reset", "cnt2", W)
+    else:
+        wave.touch("finish", state, R)
+        wave.touch("finish", state, W)
+        wave.touch("finish", "words4", W)
+        if dim == 3:
+            wave.touch("finish", "words2", W)
+        wave.barrier()  # B3
+    if wave.index == 0:
+        wave.touch("reset", counter, W)
+    wave.touch("collect", state, R)
+    wave.touch("collect", "words4", R)
+    if dim == 3:
+        wave.touch("collect", "words2", R)
+    if fenced:
+        wave.barrier()  # B4
+
+
+def sample_loop(outcomes, in_wave_disc, fenced, alternate, n_waves=3):
+    """The cooperative part of the sample loop for every combination in `outcomes` (one entry per sample: the sphere
+    call's outcome, and for the block-wide disc call the disc call's)."""
+    waves = [Wave(i) for i in range(n_waves)]
+    for wave in waves:
+        wave.barrier()  # the kernel's prologue: counters cleared, then __syncthreads
+        for k, (disc, sphere) in enumerate(outcomes):
+            if in_wave_disc:
+                # disc_tails_wave: the wave's own quarter of state[0], nothing else
+                # (a part of state[0] as round 1 of the sphere call uses it: `other`)
+                wave.touch("disc-in-wave", f"state0/quarter{wave.index}", W)
+                wave.touch("disc-in-wave", f"state0/quarter{wave.index}", R)
+            else:
+                cooperative_call(wave, 2, 0, "cnt0", disc, False, k)
+            counter = f"cnt{k & 1}" if (in_wave_disc and alternate) else "cnt1"
+            cooperative_call(wave, 3, 1, counter, sphere, in_wave_disc and fenced, k)
+        wave.barrier()  # end of the loop: the cooperative arrays become the frame stage
+    return waves
+
+
+SPHERE = ("none", "one", "two")
+DISC = ("none", "one")
+
+
+def all_outcomes(samples, with_disc):
+    per_sample = list(itertools.product(DISC if with_disc else ("none",), SPHERE))
+    return itertools.product(per_sample, repeat=samples)
+
+
+def test_block_wide_disc_call_instances_are_ordered_by_the_alternation():
+    """Frames that are not powers of two: disc call (parity 0) and sphere call (parity 1) alternate, no B4."""
+    for outcomes in all_outcomes(3, with_disc=True):
+        found = races(sample_loop(outcomes, in_wave_disc=False, fenced=False, alternate=False))
+        assert not found, (outcomes, found[:3])
+
+
+def test_in_wave_disc_instances_are_ordered_by_the_alternating_counter_and_b4():
+    """Power-of-two frames (the benchmarked instance): no barrier in the disc phase; cnt[k & 1] and B4."""
+    for outcomes in all_outcomes(4, with_disc=False):
+        found = races(sample_loop(outcomes, in_wave_disc=True, fenced=True, alternate=True))
+        assert not found, (outcomes, found[:3])
+
+
+@pytest.mark.parametrize("fenced,alternate", [(False, False), (True, False), (False, True)])
+def test_the_checker_finds_what_each_measure_is_there_for(fenced, alternate):
+    """The round-3 form (neither measure), and each measure alone: the model must report the unordered pairs --
+    the collect reads and thread 0's reset against the next park without B4; a late wave's read of the counter
+    against the next park's atomics without the alternation (in a block that left its call after B1)."""
+    found = set()
+    for outcomes in all_outcomes(3, with_disc=False):
+        for _, a, _, b in races(sample_loop(outcomes, in_wave_disc=True, fenced=fenced, alternate=alternate)):
+            found.add(tuple(sorted([(a[1], a[2]), (b[1], b[2])])))
+    if not fenced:
+        assert (("collect", "state1"), ("park", "state1")) in found  # a slow wave's collect, a fast wave's next park
+    if not fenced and not alternate:
+        assert (("park", "cnt1"), ("reset", "cnt1")) in found  # thread 0's late reset, the next park's atomics
+    if not alternate:
+        assert (("count", "cnt1"), ("park", "cnt1")) in found  # the empty-list exit: no B4 there by design
+    assert found
