@@ -109,7 +109,7 @@ struct rf_ctx {
     // small configurations replay their (host-independent) step as one hipGraph
     bool env_graph_enabled = true; // REINFOCUS_ENV_GRAPH=0 disables
     hipGraphExec_t env_graph = nullptr;
-    uint8_t *h_stage = nullptr;    // pinned: actions | pool | obs | rewards | truncated | count
+    uint8_t *h_stage = nullptr;    // pinned: the host image of the io block (EnvIo) of the replayed step
     size_t h_stage_bytes = 0;
     uint64_t env_steps = 0;
     bool env_axis = false;
@@ -180,6 +180,24 @@ struct Timed {
             (void)hipEventRecord(b, ctx->stream);
             evs->push_back(EventPair(a, b));
         }
+    }
+};
+
+// The per-step traffic of the device-resident environment as ONE block on either side -- inputs first, then outputs --
+// so that a step enqueued in one go moves it with one copy in and one copy out (a hipGraph node each, instead of two
+// and four): [pool f32 n x 2 | actions i32 n | pad to 16] [rewards f64 n | observations f32 n x 4 | count i32 | truncated u8 n]
+struct EnvIo {
+    size_t o_pool, o_actions, in_bytes, o_rewards, o_obs, o_count, o_truncated, bytes;
+    explicit EnvIo(size_t n)
+    {
+        o_pool = 0;
+        o_actions = n * 8;
+        in_bytes = (n * 12 + 15) & ~(size_t)15;
+        o_rewards = in_bytes;
+        o_obs = o_rewards + n * 8;
+        o_count = o_obs + n * 16;
+        o_truncated = o_count + 4;
+        bytes = (o_truncated + n + 15) & ~(size_t)15;
     }
 };
 
@@ -683,8 +701,32 @@ int rf_upload_frames(rf_ctx *ctx, int n, int h, int w, const uint8_t *host_in)
 
 namespace {
 
-// enqueues the focus measure of the first n frames into ctx->d_var (device)
-int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr)
+// the reduction buffers of the focus measure for n frames (grown on demand; the device-resident environment keeps a
+// pointer to the sums: it follows, and a captured step that holds the old pointers is dropped)
+int ensure_focus(rf_ctx *ctx, int n)
+{
+    if (n <= ctx->focus_cap)
+        return RF_OK;
+    drop_env_graph(ctx);
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_sums) RF_HIP(hipFree(ctx->d_sums));
+    if (ctx->d_var) RF_HIP(hipFree(ctx->d_var));
+    ctx->d_sums = nullptr;
+    ctx->d_var = nullptr;
+    ctx->env.sums = nullptr;
+    ctx->focus_cap = 0;
+    RF_HIP(hipMalloc((void **)&ctx->d_sums, (size_t)n * 2 * sizeof(unsigned long long)));
+    RF_HIP(hipMalloc((void **)&ctx->d_var, (size_t)n * sizeof(double)));
+    ctx->focus_cap = n;
+    ctx->env.sums = ctx->d_sums;
+    return RF_OK;
+}
+
+// enqueues the focus measure of the first n frames: sums into ctx->d_sums, variances into ctx->d_var (device).
+// in_env_step: the sums were zeroed by the environment kernel before (env_pre_kernel / env_reset_kernel) and the
+// variance is taken from them by the one after (env_post_kernel / env_reset_post_kernel, the same expression as
+// focus_finalize): no memset and no finalize launch -- two nodes less per focus measure of a replayed step.
+int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr, bool in_env_step = false)
 {
     // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
     const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
@@ -692,18 +734,11 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
     const int band = quad ? rf::kBandQ : rf::kBand;
     const size_t lds = quad ? lds_quad : ((((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15);
     RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);
-    if (n > ctx->focus_cap) {
-        RF_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->d_sums) RF_HIP(hipFree(ctx->d_sums));
-        if (ctx->d_var) RF_HIP(hipFree(ctx->d_var));
-        ctx->d_sums = nullptr;
-        ctx->d_var = nullptr;
-        ctx->focus_cap = 0;
-        RF_HIP(hipMalloc((void **)&ctx->d_sums, (size_t)n * 2 * sizeof(unsigned long long)));
-        RF_HIP(hipMalloc((void **)&ctx->d_var, (size_t)n * sizeof(double)));
-        ctx->focus_cap = n;
-    }
-    RF_HIP(hipMemsetAsync(ctx->d_sums, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
+    int rc = ensure_focus(ctx, n);
+    if (rc != RF_OK)
+        return rc;
+    if (!in_env_step)
+        RF_HIP(hipMemsetAsync(ctx->d_sums, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
     {
         Timed timed(ctx, &ctx->ev_focus);
         const int gx = (h + band - 1) / band;
@@ -722,8 +757,9 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
             else
                 hipLaunchKernelGGL(rf::focus_kernel, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
         }
-        hipLaunchKernelGGL(rf::focus_finalize, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_sums,
-                           ctx->d_var, n, (unsigned long long)h * (unsigned long long)w);
+        if (!in_env_step)
+            hipLaunchKernelGGL(rf::focus_finalize, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_sums,
+                               ctx->d_var, n, (unsigned long long)h * (unsigned long long)w);
     }
     RF_HIP(hipGetLastError());
     return RF_OK;
@@ -958,9 +994,9 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_state = take(n * 8), o_steps = take(n * 4), o_div = take(n * 4), o_last = take(n * 4),
                  o_oldw = take(n * 8), o_oldf = take(n * 4), o_cam = take(n * 36), o_rect = take(n * 8),
-                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_cnt = take(4),
-                 o_obs = take(n * 16), o_rew = take(n * 8), o_trunc = take(n), o_done = take(n),
-                 o_act = take(n * 4), o_pool = take(n * 8);
+                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_done = take(n);
+    const EnvIo io(n);
+    const size_t o_io = take(io.bytes);
     RF_HIP(hipMalloc(&ctx->env_block, off));
     RF_HIP(hipMemsetAsync(ctx->env_block, 0, off, ctx->stream));
     char *base = (char *)ctx->env_block;
@@ -976,13 +1012,13 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     s.cam_dyn2 = (float *)(base + o_cam2);
     s.rect2 = (float *)(base + o_rect2);
     s.done_index = (int *)(base + o_didx);
-    s.done_count = (int *)(base + o_cnt);
-    s.obs = (float *)(base + o_obs);
-    s.reward = (double *)(base + o_rew);
-    s.truncated = (uint8_t *)(base + o_trunc);
+    s.done_count = (int *)(base + o_io + io.o_count);
+    s.obs = (float *)(base + o_io + io.o_obs);
+    s.reward = (double *)(base + o_io + io.o_rewards);
+    s.truncated = (uint8_t *)(base + o_io + io.o_truncated);
     s.done = (uint8_t *)(base + o_done);
-    ctx->d_actions = (int *)(base + o_act);
-    ctx->d_pool = (float *)(base + o_pool);
+    ctx->d_actions = (int *)(base + o_io + io.o_actions);
+    ctx->d_pool = (float *)(base + o_io + io.o_pool);
 
     rf::EnvConfig &c = ctx->env_cfg;
     c.n = cfg->n;
@@ -1009,7 +1045,14 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
         c.cam_v[i] = cfg->cam_v[i];
         c.cam_w[i] = cfg->cam_w[i];
     }
+    c.frame_pixels = (unsigned long long)cfg->frame_height * (unsigned long long)cfg->frame_height;
     ctx->env_host = *cfg;
+    {
+        int rc = ensure_focus(ctx, cfg->n); // (the environment kernels zero and read the sums themselves)
+        if (rc != RF_OK)
+            return rc;
+        ctx->env.sums = ctx->d_sums;
+    }
     ctx->cs = rf::CamStatic{cfg->look_from[0], cfg->look_from[1], cfg->look_from[2], cfg->cam_u[0], cfg->cam_u[1],
                             cfg->cam_u[2],     cfg->cam_v[0],     cfg->cam_v[1],     cfg->cam_v[2], cfg->lens_radius,
                             0.0f,              0.0f,              0};
@@ -1045,11 +1088,11 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env, (const int *)nullptr);
     int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
     if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
     if (rc != RF_OK)
         return rc;
     hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)ctx->d_var, 1);
+                       (const double *)nullptr, 1);
     RF_HIP(hipGetLastError());
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
     RF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1072,35 +1115,48 @@ bool env_one_sync(const rf_ctx *ctx)
 // the unused ones, whose blocks exit at once), the downloads.  Used directly and under stream
 // capture.
 int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, float *obs, double *rewards,
-                     uint8_t *truncated, int *count)
+                     uint8_t *truncated, int *count, uint8_t *host_io = nullptr)
 {
+    // host_io: the host side is an image of the device's io block (EnvIo: the pinned staging buffer of the replayed
+    // step) -- one copy in, one copy out; otherwise the caller's six separate arrays
     const rf_env_config &h = ctx->env_host;
     const int n = h.n, fh = h.frame_height;
     const dim3 grid((n + 255) / 256), block(256);
-    RF_HIP(hipMemcpyAsync(ctx->d_actions, actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    RF_HIP(hipMemcpyAsync(ctx->d_pool, pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const EnvIo io((size_t)n);
+    uint8_t *const d_io = (uint8_t *)ctx->d_pool; // (the io block starts with the pool)
+    if (host_io) {
+        RF_HIP(hipMemcpyAsync(d_io, host_io, io.in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        RF_HIP(hipMemcpyAsync(ctx->d_actions, actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const int *)ctx->d_actions);
     int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
     if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
     if (rc != RF_OK)
         return rc;
     hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)ctx->d_var, 0);
+                       (const double *)nullptr, 0);
     hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const float *)ctx->d_pool, rf::kEnvResetBoth);
     rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis, false);
     if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2);
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2, true);
     if (rc != RF_OK)
         return rc;
     hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)ctx->d_var);
-    RF_HIP(hipMemcpyAsync(count, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipMemcpyAsync(rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipMemcpyAsync(truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    RF_HIP(hipMemcpyAsync(obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+                       (const double *)nullptr);
+    if (host_io) {
+        RF_HIP(hipMemcpyAsync(host_io + io.o_rewards, d_io + io.o_rewards, io.bytes - io.o_rewards, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    } else {
+        RF_HIP(hipMemcpyAsync(count, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        RF_HIP(hipMemcpyAsync(obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
     return RF_OK;
 }
 
@@ -1118,11 +1174,11 @@ int env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_reward
                        (const int *)ctx->d_actions);
     int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
     if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode);
+        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
     if (rc != RF_OK)
         return rc;
     hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)ctx->d_var, 0);
+                       (const double *)nullptr, 0);
     hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const float *)nullptr, rf::kEnvResetRank);
     RF_HIP(hipGetLastError());
@@ -1145,11 +1201,11 @@ int env_step_end(rf_ctx *ctx, const float *host_pool, int k, float *host_obs)
                            (const float *)ctx->d_pool, rf::kEnvResetApply);
         int rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis);
         if (rc == RF_OK)
-            rc = launch_focus(ctx, k, fh, fh, h.gray_mode);
+            rc = launch_focus(ctx, k, fh, fh, h.gray_mode, nullptr, true);
         if (rc != RF_OK)
             return rc;
         hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
-                           ctx->env, (const double *)ctx->d_var);
+                           ctx->env, (const double *)nullptr);
         RF_HIP(hipGetLastError());
     }
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1181,8 +1237,8 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     // synchronisation.  Large ones size the auto-reset launch by the count, which costs one round
     // trip and saves up to a few hundred thousand empty blocks.
     if (env_one_sync(ctx)) {
-        const size_t o_pool = (size_t)n * 4, o_obs = o_pool + (size_t)n * 8, o_rew = o_obs + (size_t)n * 16,
-                     o_tru = o_rew + (size_t)n * 8, o_cnt = (o_tru + (size_t)n + 7) & ~(size_t)7, bytes = o_cnt + 8;
+        const EnvIo io((size_t)n);
+        const size_t bytes = io.bytes;
         const bool graph = ctx->env_graph_enabled && !ctx->timing && ctx->env_steps >= 1;
         if (!graph) {
             int rc = enqueue_env_step(ctx, host_actions, host_pool, host_obs, host_rewards, host_truncated, &k);
@@ -1211,8 +1267,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                 hipError_t he = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
                 int rc = RF_OK;
                 if (he == hipSuccess) {
-                    rc = enqueue_env_step(ctx, (const int32_t *)st, (const float *)(st + o_pool), (float *)(st + o_obs),
-                                          (double *)(st + o_rew), st + o_tru, (int *)(st + o_cnt));
+                    rc = enqueue_env_step(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
                     he = hipStreamEndCapture(ctx->stream, &captured);
                     if (he == hipSuccess && rc == RF_OK && ctx->env_graph_fail_once) {
                         ctx->env_graph_fail_once = false; // test hook: behave as if instantiation had failed
@@ -1241,14 +1296,14 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     return RF_OK;
                 }
             }
-            memcpy(st, host_actions, (size_t)n * 4);
-            memcpy(st + o_pool, host_pool, (size_t)n * 8);
+            memcpy(st + io.o_actions, host_actions, (size_t)n * 4);
+            memcpy(st + io.o_pool, host_pool, (size_t)n * 8);
             RF_HIP(hipGraphLaunch(ctx->env_graph, ctx->stream));
             RF_HIP(hipStreamSynchronize(ctx->stream));
-            memcpy(host_obs, st + o_obs, (size_t)n * 16);
-            memcpy(host_rewards, st + o_rew, (size_t)n * 8);
-            memcpy(host_truncated, st + o_tru, (size_t)n);
-            k = *(const int *)(st + o_cnt);
+            memcpy(host_obs, st + io.o_obs, (size_t)n * 16);
+            memcpy(host_rewards, st + io.o_rewards, (size_t)n * 8);
+            memcpy(host_truncated, st + io.o_truncated, (size_t)n);
+            k = *(const int *)(st + io.o_count);
             ctx->env_last_branch = RF_ENV_BRANCH_GRAPH;
         }
         // what this step really rendered: all n environments, then the k that ended (the other slots of the

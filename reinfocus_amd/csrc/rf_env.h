@@ -35,6 +35,7 @@ struct EnvConfig {
     // camera / world packing
     double half_width, half_height, tan_half_r; // Python floats
     float look_from[3], cam_u[3], cam_v[3], cam_w[3];
+    unsigned long long frame_pixels; // h * w of the frames the focus measure reduces
 };
 
 struct EnvState {            // all device arrays, length n unless noted
@@ -53,7 +54,19 @@ struct EnvState {            // all device arrays, length n unless noted
     double *reward;          // [n]
     uint8_t *truncated;      // [n]
     uint8_t *done;           // [n] scratch
+    unsigned long long *sums; // [n][2] the focus measure's (sum, sum of squares): zeroed here before a measure, read after
 };
+
+// ndarray.var() of a frame's Laplacian from its exact integer sums -- focus_finalize's expression (rf_kernels.h); the
+// environment kernels take the variance from the sums themselves, which saves the replayed step a launch per measure
+__device__ __forceinline__ double env_variance(const EnvConfig &c, const EnvState &s, int slot)
+{
+    const unsigned long long s1 = s.sums[2 * slot], s2 = s.sums[2 * slot + 1];
+    const unsigned __int128 num = (unsigned __int128)c.frame_pixels * s2 - (unsigned __int128)s1 * s1;
+    const double dn = (double)c.frame_pixels;
+    return (double)(unsigned long long)num / (dn * dn);
+}
+
 
 // camera.py:144-179 + world.py:110-123 for one environment
 __device__ __forceinline__ void pack_scene(const EnvConfig &c, float target, float fp, float *dyn, float *rc)
@@ -99,6 +112,8 @@ __global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
         s.last_diff[e] = fabsf(target - focus);
     }
     pack_scene(c, target, focus, s.cam_dyn + 9 * e, s.rect + 2 * e);
+    s.sums[2 * e] = 0; // (the focus measure of the render that follows accumulates into them)
+    s.sums[2 * e + 1] = 0;
 }
 
 __device__ __forceinline__ float normalize1(const EnvConfig &c, int k, float v)
@@ -107,13 +122,14 @@ __device__ __forceinline__ float normalize1(const EnvConfig &c, int k, float v)
 }
 
 // observe -> reward -> done flags (vector_environment.py:128-135); `first` = reset() call
+// focus_values == nullptr: the variance comes from the sums the focus kernel left (env_variance)
 __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_values, int first)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.n)
         return;
     const float target = s.state[2 * e], focus = s.state[2 * e + 1];
-    const float w0 = focus, w1 = (float)focus_values[e];
+    const float w0 = focus, w1 = (float)(focus_values ? focus_values[e] : env_variance(c, s, e));
     float d0 = 0.0f, d1 = 0.0f;
     if (!first) {
         d0 = w0 - s.old_wrapped[2 * e];
@@ -172,8 +188,11 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
     __shared__ int running;
     if (mode == kEnvResetApply) {
         const int count = *s.done_count;
-        for (int r = (int)threadIdx.x; r < count; r += 1024)
+        for (int r = (int)threadIdx.x; r < count; r += 1024) {
             env_apply_reset(c, s, pool, r, s.done_index[r]);
+            s.sums[2 * r] = 0; // (the auto-reset's focus measure accumulates into slot r)
+            s.sums[2 * r + 1] = 0;
+        }
         return;
     }
     if (threadIdx.x == 0)
@@ -207,9 +226,14 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
     if (threadIdx.x == 0)
         *s.done_count = running;
     // the auto-reset render is enqueued for all n slots: mark the ones it has to skip
-    if (mode == kEnvResetBoth)
+    if (mode == kEnvResetBoth) {
         for (int r = running + (int)threadIdx.x; r < c.n; r += 1024)
             s.rect2[2 * r] = __builtin_bit_cast(float, kSkipEnvBits);
+        for (int r = (int)threadIdx.x; r < running; r += 1024) { // (the auto-reset's focus measure accumulates into slot r)
+            s.sums[2 * r] = 0;
+            s.sums[2 * r + 1] = 0;
+        }
+    }
 }
 
 // Scene of k given states as rows 0..k-1 of the compacted set (cam_dyn2 / rect2): the packing half of
@@ -232,7 +256,7 @@ __global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *foc
         return;
     const int e = s.done_index[r];
     const float focus = s.state[2 * e + 1];
-    const float w0 = focus, w1 = (float)focus_values[r];
+    const float w0 = focus, w1 = (float)(focus_values ? focus_values[r] : env_variance(c, s, r));
     s.old_wrapped[2 * e] = w0;
     s.old_wrapped[2 * e + 1] = w1;
     s.obs[4 * e] = normalize1(c, 0, w0);
