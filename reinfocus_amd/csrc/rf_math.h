@@ -58,13 +58,6 @@ RF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s)
 #endif
 }
 
-#ifndef RF_SHL64
-#define RF_SHL64 1
-#endif
-#ifndef RF_BITOP3
-#define RF_BITOP3 1
-#endif
-
 // result = s0 + s1 (as two words), then the xoroshiro128+ 55/14/36 state update:
 // one v_lshl_add_u64 for the sum, v_alignbit_b32 funnel shifts for everything else
 // (13 VALU instructions; checked in the ISA).
@@ -80,7 +73,7 @@ RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
     // rotl(s0, 55) == rotr(s0, 9)
     const uint32_t ro_lo = funnel_r(a_hi, a_lo, 9), ro_hi = funnel_r(a_lo, a_hi, 9);
     // s1 << 14
-#if defined(__HIP_DEVICE_COMPILE__) && RF_SHL64
+#if defined(__HIP_DEVICE_COMPILE__)
     // one 64-bit shift issues in the time of one v_alignbit_b32 (tools/ubench)
     uint64_t sh;
     asm("v_lshlrev_b64 %0, 14, %1" : "=v"(sh) : "v"((((uint64_t)x_hi) << 32) | x_lo));
@@ -88,7 +81,7 @@ RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
 #else
     const uint32_t sh_lo = x_lo << 14, sh_hi = funnel_r(x_hi, x_lo, 18);
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && RF_BITOP3
+#if defined(__HIP_DEVICE_COMPILE__)
     // gfx950's three-input boolean op as a three-way xor (truth table 0x96): one instruction per word
     g.a_lo = __builtin_amdgcn_bitop3_b32(ro_lo, x_lo, sh_lo, 0x96);
     g.a_hi = __builtin_amdgcn_bitop3_b32(ro_hi, x_hi, sh_hi, 0x96);
@@ -141,12 +134,8 @@ RF_HD float unit_f32_int(uint64_t r)
 // two exact u32 conversions -- then a single f64->f32 RNE (the very cast numba performs)
 // and an exact power-of-two scaling.  Four instructions of the 4-cycle class, no rare path;
 // measured 2.6 % faster end to end than a two-f32 split with sticky bits (tools/ubench).
-#ifndef RF_CONV_MAGIC
-#define RF_CONV_MAGIC 1
-#endif
 RF_HD float unit_f32_scaled64(uint32_t r_hi, uint32_t r_lo)
 {
-#if RF_CONV_MAGIC
     // The same exact 53-bit integer without the two u32 -> f64 conversions (slow-path instructions on
     // gfx950, like the f64 fma): the bit patterns {0x45300000, hi} and {0x43300000, lo & ~0x7FF} ARE the
     // doubles 2^84 + hi 2^32 and 2^52 + (lo & ~0x7FF); (A - (2^84 + 2^52)) is exact (a multiple of 2^32
@@ -158,9 +147,6 @@ RF_HD float unit_f32_scaled64(uint32_t r_hi, uint32_t r_lo)
     __builtin_memcpy(&a, &a_bits, 8);
     __builtin_memcpy(&b, &b_bits, 8);
     const double d = (a - 19342813118337666422669312.0 /* 2^84 + 2^52 */) + b;
-#else
-    const double d = __builtin_fma((double)r_hi, 4294967296.0, (double)(r_lo & 0xFFFFF800u));
-#endif
     return (float)d; // < 2^64: the scale is the consumer's (an exact power of two in its fma or product)
 }
 
@@ -172,11 +158,7 @@ RF_HD float rng_uniform64(Rng &g)
 {
     uint32_t hi, lo;
     rng_next(g, hi, lo);
-#ifndef RF_UNIFORM_LITERAL
     return unit_f32_scaled64(hi, lo);
-#else
-    return ldexp_pow2(unit_f32_literal(((uint64_t)hi << 32) | lo), 64);
-#endif
 }
 
 RF_HD float rng_uniform(Rng &g) { return rng_uniform64(g) * kTwoM64; } // exact scaling
@@ -258,13 +240,9 @@ RF_HD int checker_sign(float u, const CheckerTable &tab)
 
 // sin(32 pi u) * sin(32 pi v) > 0 for u, v >= 0: the common case (neither 32u nor 32v an
 // integer) is one parity test of trunc(32u) ^ trunc(32v); exact integers take the table.
-#ifndef RF_CHECKER_FP
-#define RF_CHECKER_FP 1
-#endif
 RF_HD bool checker_red(float u, float v, const CheckerTable &tab)
 {
     const float mu = u * 32.0f, mv = v * 32.0f;
-#if RF_CHECKER_FP
     // The same parity without conversions and with one compare (float <-> int conversions and compares
     // issue on gfx950's slow path, float adds and logic ops do not): for 0 <= m <= 32, a = m + 2^23 is
     // m rounded to an integer r (ties to even) whose parity is the lowest bit of a's pattern; d = m - r
@@ -282,12 +260,6 @@ RF_HD bool checker_red(float u, float v, const CheckerTable &tab)
     __builtin_memcpy(&bdu, &du, 4);
     __builtin_memcpy(&bdv, &dv, 4);
     return (((bau ^ bav) ^ ((bdu ^ bdv) >> 31)) & 1u) == 0u;
-#else
-    const int ku = (int)mu, kv = (int)mv; // trunc == floor: u, v >= 0
-    if (__builtin_expect(mu == (float)ku || mv == (float)kv, 0))
-        return (checker_sign(u, tab) * checker_sign(v, tab)) > 0;
-    return ((ku ^ kv) & 1) == 0;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -325,10 +297,6 @@ struct Colour {
 // accepted attempt is converted exactly after the loop, once.
 constexpr float kTwoM31 = 4.656612873077393e-10f; // 2^-31
 
-#ifndef RF_APPROX_BITS
-#define RF_APPROX_BITS 1
-#endif
-#if RF_APPROX_BITS
 // gfx950 issues v_cvt_f32_u32 on its slow VALU path (4.3 cycles per wave, like every conversion,
 // compare, shift-left and three-operand integer op) but v_lshrrev_b32 and v_fma_f32 on the fast one
 // (2.4-2.9 cycles, and float fast-path ops overlap with slow-path ones): tools/ubench/pairbench.
@@ -347,10 +315,6 @@ RF_HD float approx_pm1(uint32_t r_hi)
     __builtin_memcpy(&sub, &k, 4);
     return __builtin_fmaf(sub, 1.7014118346046923e+38f /* 2^127 */, -1.0f);
 }
-#else
-constexpr float kAcceptBand = 7.62939453125e-06f;  // 2^-17
-RF_HD float approx_pm1(uint32_t r_hi) { return __builtin_fmaf((float)r_hi, kTwoM31, -1.0f); }
-#endif
 // == RN(xi*2f - 1f): the scalings by powers of two are exact
 RF_HD float exact_pm1(uint32_t r_hi, uint32_t r_lo)
 {
@@ -389,26 +353,6 @@ RF_HD float disc_attempt_sq(Rng &g, uint32_t w[4])
         sq = d0 + d1;
     }
     return sq;
-}
-
-// "Not certainly rejected": one compare.  An attempt whose approximate squared length is >= 1 + band is
-// rejected by the reference too (the two lengths differ by less than the band); anything else leaves
-// the loop, and the caller settles it with the exact expression AFTER the exact conversion it performs
-// anyway (disc_exact_ok) -- if that says "rejected" (the candidate was inside the band and on the wrong
-// side: ~1e-5 of the attempts) the caller continues with disc_attempt.  Same decisions, one slow-path
-// compare and no band branch per attempt.
-RF_HD bool disc_attempt_maybe(Rng &g, uint32_t w[4])
-{
-    rng_next(g, w[0], w[1]);
-    rng_next(g, w[2], w[3]);
-    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]);
-    return __builtin_fmaf(ta, ta, tb * tb) < 1.0f + kAcceptBand;
-}
-// camera.py:240: the reference's own test on the exactly converted candidate
-RF_HD bool disc_exact_ok(float p0, float p1)
-{
-    const float d0 = p0 * p0, d1 = p1 * p1;
-    return d0 + d1 < 1.0f;
 }
 
 RF_HD void disc_finish(const uint32_t w[4], float &p0, float &p1)
@@ -452,16 +396,6 @@ RF_HD float sphere_attempt_sq(Rng &g, uint32_t w[6]) // see disc_attempt_sq
         sq = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5]));
     return sq;
 }
-
-RF_HD bool sphere_attempt_maybe(Rng &g, uint32_t w[6]) // see disc_attempt_maybe
-{
-    rng_next(g, w[0], w[1]);
-    rng_next(g, w[2], w[3]);
-    rng_next(g, w[4], w[5]);
-    const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]), tc = approx_pm1(w[4]);
-    return __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc)) < 1.0f + kAcceptBand;
-}
-RF_HD bool sphere_exact_ok(float q0, float q1, float q2) { return sq_len(q0, q1, q2) < 1.0f; } // physics.py:31
 
 RF_HD void sphere_finish(const uint32_t w[6], float &q0, float &q1, float &q2)
 {

@@ -210,18 +210,6 @@ long hs_check_accept(const uint64_t *words, long n, int dims, long *in_band)
         }
         if (got != want)
             ++bad;
-        // the one-compare form (disc_attempt_maybe / sphere_attempt_maybe + the exact test after the
-        // conversion): "maybe" must never be false for a candidate the reference accepts, and
-        // maybe && exact must be the reference's decision
-        {
-            const bool maybe = sq < 1.0f + kAcceptBand;
-            float e[3] = {0, 0, 0};
-            for (int k = 0; k < dims; ++k)
-                e[k] = exact_pm1((uint32_t)(words[i * dims + k] >> 32), (uint32_t)words[i * dims + k]);
-            const bool exact = dims == 2 ? disc_exact_ok(e[0], e[1]) : sphere_exact_ok(e[0], e[1], e[2]);
-            if ((maybe && exact) != want || (want && !maybe))
-                ++bad;
-        }
         // the squared-length form (disc_attempt_sq / sphere_attempt_sq): the approximate length outside the band,
         // the reference's own inside; its comparison with 1 must be the reference's decision
         {
