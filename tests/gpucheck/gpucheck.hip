@@ -84,60 +84,6 @@ extern "C" int gc_check_approx_pm1(unsigned long long *out)
     return 0;
 }
 
-// render_kernel_coop2 can accumulate the colour sums of its pixel sets with ds_add_f32 (RF_COLOUR_ATOMIC: LDS float
-// atomics, no return value -- measured 2.5x slower, off).  That is the reference's float32 addition only if the LDS
-// unit rounds to nearest even like v_add_f32: checked here for sums and addends of the kind the kernel has (a running
-// sum in [0, 128], addends in [0, 1] including 0, values one ulp from 0 / 0.5 / 1).
-__device__ __forceinline__ uint32_t mix32(uint32_t x)
-{
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
-__global__ void check_lds_add_kernel(unsigned long long *bad, uint32_t rounds)
-{
-    __shared__ float acc[256];
-    unsigned long long mine = 0;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t id = (blockIdx.x * rounds + r) * 256u + threadIdx.x;
-        const uint32_t h0 = mix32(id * 2u + 1u), h1 = mix32(id * 2u + 2u);
-        // running sum: a few-sample sum of values in [0, 1] scaled up to 128
-        float sum = (float)(h0 >> 8) * (1.0f / 16777216.0f) * (float)(1u << (h0 & 7u));
-        float add = (float)(h1 >> 8) * (1.0f / 16777216.0f);
-        switch (h1 & 7u) { // special addends
-        case 0: add = 0.0f; break;
-        case 1: add = __uint_as_float(0x33000000u + ((h1 >> 3) & 0xFFFFu)); break; // around 2^-25
-        case 2: add = __uint_as_float(0x3F000000u - 1u + ((h1 >> 3) & 3u)); break;  // around 0.5
-        case 3: add = __uint_as_float(0x3F800000u - 2u + ((h1 >> 3) & 3u)); break;  // around 1
-        default: break;
-        }
-        if ((h0 & 0x700u) == 0)
-            sum = 0.0f;
-        acc[threadIdx.x] = sum;
-        atomicAdd(&acc[threadIdx.x], add); // ds_add_f32
-        const float got = acc[threadIdx.x];
-        float want = sum + add;
-        asm volatile("" : "+v"(want));
-        if (__float_as_uint(got) != __float_as_uint(want))
-            ++mine;
-    }
-    if (mine)
-        atomicAdd(bad, mine);
-}
-
-extern "C" int gc_check_lds_add(unsigned long long *out)
-{
-    unsigned long long *d_bad;
-    if (hipMalloc((void **)&d_bad, 8) != hipSuccess || hipMemset(d_bad, 0, 8) != hipSuccess)
-        return -1;
-    hipLaunchKernelGGL(check_lds_add_kernel, dim3(8192), dim3(256), 0, 0, d_bad, 512u); // 2^30 pairs
-    if (hipDeviceSynchronize() != hipSuccess)
-        return -2;
-    if (hipMemcpy(out, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess)
-        return -3;
-    (void)hipFree(d_bad);
-    return 0;
-}
-
 // ---- probes of the general renderer's float64 library calls (see probe_general.h) ----------
 __global__ void probe_f64_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
 {

@@ -367,18 +367,6 @@ def test_rejection_candidate_from_subnormal_bits_is_exact(native):
     assert bad.value == 0, f"{bad.value} of 2^32 candidates differ"
 
 
-def test_lds_float_atomic_add_is_the_float32_addition(native):
-    """The RF_COLOUR_ATOMIC build of render_kernel_coop2 (measured, not shipped) adds a sample's colour to the sums of
-    its pixel sets with ds_add_f32: 2^30 (sum, addend) pairs of the kind the kernel has must give the bits of the plain
-    float32 addition."""
-    import ctypes
-
-    lib = ctypes.CDLL(helpers.built("tests/gpucheck", "libgpucheck.so"))
-    bad = ctypes.c_ulonglong(0)
-    assert lib.gc_check_lds_add(ctypes.byref(bad)) == 0
-    assert bad.value == 0, f"{bad.value} of 2^30 sums differ"
-
-
 def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
     """Renders `scene` in a child process whose environment selects another kernel / build of
     the library (the selection is read once, at rf_create); returns frames and final states."""
