@@ -61,6 +61,7 @@ SYMBOLS = (
     "rf_env_last_step_branch",
     "rf_render_kernel_name",
     "rf_pixels_rendered",
+    "rf_general_redo_pixels",
 )
 
 
@@ -152,6 +153,8 @@ def load():
     lib.rf_render_kernel_name.argtypes = [vp]
     lib.rf_pixels_rendered.restype = ctypes.c_ulonglong
     lib.rf_pixels_rendered.argtypes = []
+    lib.rf_general_redo_pixels.restype = ctypes.c_uint
+    lib.rf_general_redo_pixels.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -420,6 +423,10 @@ class Context:
 
     def render_kernel_name(self):
         return self._lib.rf_render_kernel_name(self._h).decode()
+
+    def general_redo_pixels(self):
+        """Pixels the last render_general call left to its fix-up kernel (rf_general_redo_pixels)."""
+        return int(self._lib.rf_general_redo_pixels(self._h))
 
     def env_states(self):
         out = np.empty((self._env_n, 2), dtype=np.float32)

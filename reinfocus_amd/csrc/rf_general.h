@@ -331,6 +331,12 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
 struct GeneralCamera {
     float f[18]; // lower_left, horizontal, vertical, origin, u, v
     double lens_radius;
+    // per-environment constants of general_ray for the cooperative single-rectangle kernel (rf_general_rect.h), which
+    // reads them into scalar registers instead of keeping 18 vector registers of loop invariants: float64(u),
+    // float64(v) (vector.py:190 promotes the float32 components when it scales them by the float64 lens offsets) and
+    // the leading `0 + a` of the two three-term sums
+    double u64[3], v64[3];
+    float origin0[3], lower_left0[3];
 };
 
 RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
@@ -339,6 +345,12 @@ RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
     for (int k = 0; k < 18; ++k)
         c.f[k] = (float)cam[k];
     c.lens_radius = cam[18];
+    for (int k = 0; k < 3; ++k) {
+        c.u64[k] = (double)c.f[12 + k];
+        c.v64[k] = (double)c.f[15 + k];
+        c.origin0[k] = 0.0f + c.f[9 + k];
+        c.lower_left0[k] = 0.0f + c.f[k];
+    }
     return c;
 }
 

@@ -90,6 +90,26 @@ def test_general_renderer_beyond_one_launch(ctx, oracle):
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
+def test_one_rectangle_worlds_beyond_one_launch(ctx, oracle):
+    """The same for worlds of one rectangle (render_general_rect_kernel + fix-up list per chunk): 65 540 environments of
+    8 x 4 pixels (dword rows: the staged store path) and of 5 x 5 (byte stores), second chunk included."""
+    for h, w in ((4, 8), (5, 5)):
+        n, spp = 65_540, 2
+        cameras8, (params8, types8, sizes8) = _random_one_rectangle_worlds(np.random.default_rng(9), 8)
+        reps = -(-n // 8)
+        cameras = np.ascontiguousarray(np.tile(cameras8, (reps, 1))[:n])
+        params = np.ascontiguousarray(np.tile(params8, (reps, 1, 1))[:n])
+        types = np.ascontiguousarray(np.tile(types8, (reps, 1))[:n])
+        sizes = np.ascontiguousarray(np.tile(sizes8, reps)[:n])
+        st = oracle.seed_states(n * h * w, 0)
+        want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+        got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+        assert ctx.render_kernel_name().startswith("render_general_rect_kernel")
+        assert np.array_equal(got[:65_535], want[:65_535]), "first chunk"
+        assert np.array_equal(got[65_535:], want[65_535:]), "second chunk"
+        assert np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
 def test_reference_render_tests():
     """tests/graphics/render_test.py:27-80 through reinfocus_amd.graphics.render.render."""
     from reinfocus_amd.graphics import camera, render, shape_factory as sf, world
@@ -126,6 +146,78 @@ def test_general_equals_fast_path_for_one_rectangle(ctx, oracle):
     got = ctx.render_general(cams.device_data(), p, t, s, 64, 64, 5)
     assert np.array_equal(got, want)
     assert np.array_equal(ctx.get_states(0, 2 * 64 * 64), st)
+
+
+def _random_one_rectangle_worlds(rng, n):
+    """n environments of one rectangle each (off-centre, any size and checker frequencies) seen by cameras that look from
+    off the axis through apertures of every size: the worlds render_general_rect_kernel takes."""
+    from reinfocus_amd.graphics import camera, shape, world
+
+    cams, envs = [], []
+    for _ in range(n):
+        cams.append(camera.make_gpu_camera(aperture=rng.uniform(0.0, 0.5), focus_distance=rng.uniform(4, 12),
+                                           vfov=rng.uniform(20, 55), aspect_ratio=rng.uniform(0.7, 1.8),
+                                           look_from=(rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2))))
+        z = -rng.uniform(3, 12)
+        x, y, sx, sy = rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(0.3, 3.0), rng.uniform(0.3, 3.0)
+        tex = (int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+        envs.append([shape.rectangle(shape.v2f(x - sx, x + sx), shape.v2f(y - sy, y + sy), z, shape.v2f(*tex))])
+    return camera.Cameras(*cams).device_data(), world.Worlds(*envs).device_data()
+
+
+@pytest.mark.parametrize("n,h,w,spp,seed", [(5, 40, 56, 6, 1), (3, 96, 64, 8, 2), (7, 33, 35, 3, 3), (4, 128, 128, 9, 4),
+                                           (2, 300, 300, 4, 5), (3, 16, 260, 5, 6), (2, 7, 500, 2, 7), (6, 64, 64, 20, 8)])
+def test_one_rectangle_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, oracle, n, h, w, spp, seed):
+    """Worlds of one rectangle per environment go through render_general_rect_kernel (rf_general_rect.h: the fast path's
+    organisation with the general renderer's arithmetic) + the fix-up kernel: frames and final RNG states bit-identical to
+    the oracle's general path for power-of-two and other frames, widths that are not multiples of four (byte stores),
+    partial tiles, frames wider than high, and switching back to the literal kernel gives the same."""
+    rng = np.random.default_rng(seed)
+    cameras, (params, types, sizes) = _random_one_rectangle_worlds(rng, n)
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+    got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+    assert ctx.render_kernel_name().startswith("render_general_rect_kernel")
+    differing = np.any(got != want, axis=-1).sum()
+    assert differing == 0, f"{differing} of {n * h * w} pixels differ"
+    assert np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
+def test_every_abstention_of_the_rectangle_kernel_is_repaired(oracle, tmp_path):
+    """The single-rectangle kernel abstains on a pixel whose checker colour float32 cannot decide, or whose scattered ray
+    grazes the plane it left, and the fix-up kernel renders those pixels literally.  That happens about once in 10^4
+    pixels, and a decision inside the margin is almost always right anyway: an abstention that got lost would go
+    unnoticed.  tests/gpucheck builds the library with RF_TEST_DOUBT -- a fifth of the checker decisions and a sixteenth
+    of the scattered rays abstain, and whatever abstains is computed WRONG on purpose (inverted sign, mirrored direction)
+    -- and a child process renders with it: most pixels are listed, and frames and RNG states must still be the
+    oracle's."""
+    import subprocess
+    import sys
+
+    so = helpers.built("tests/gpucheck", "libreinfocus_doubt.so")
+    rng = np.random.default_rng(21)
+    out = tmp_path / "out.npz"
+    for n, h, w, spp in ((4, 64, 64, 6), (3, 40, 52, 5)):
+        cameras, (params, types, sizes) = _random_one_rectangle_worlds(rng, n)
+        np.savez(tmp_path / "scene.npz", cameras=cameras, params=params, types=types, sizes=sizes)
+        script = (
+            "import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from reinfocus_amd import _native\n"
+            "d = np.load(%r)\n"
+            "c = _native.Context(0)\n"
+            "f = c.render_general(d['cameras'], d['params'], d['types'], d['sizes'], %d, %d, %d)\n"
+            "np.savez(%r, frames=f, states=c.get_states(0, %d), redo=c.general_redo_pixels(), kernel=c.render_kernel_name())\n"
+            "c.close()\n"
+        ) % (helpers.ROOT, str(tmp_path / "scene.npz"), h, w, spp, str(out), n * h * w)
+        subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_HIP_LIB=so))
+        got = np.load(out)
+        st = oracle.seed_states(n * h * w, 0)
+        want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+        assert str(got["kernel"]).startswith("render_general_rect_kernel")
+        assert int(got["redo"]) > n * h * w // 20, "the test build should abstain on many pixels"
+        assert np.array_equal(got["frames"], want)
+        assert np.array_equal(got["states"], st)
 
 
 def test_device_math_library_reaches_the_same_float32():

@@ -59,6 +59,7 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         print(f"{label}: {n} envs x {frame}^2 x {spp} spp: {dt * 1e3:.2f} ms per render "
               f"(incl. re-seeding), {n * frame * frame * spp / dt / 1e9:.2f} G samples/s, "
+              f"{ctx.general_redo_pixels() / (n * frame * frame):.4%} of the pixels fixed up, "
               f"{ctx.render_kernel_name()}", flush=True)
     ctx.close()
 
