@@ -254,8 +254,15 @@ int rf_env_render(rf_ctx *ctx, int frame_height, int spp, uint8_t *host_out);
  * prints: episode_ender.py:191-207, :646-656). */
 int rf_env_get_counters(rf_ctx *ctx, int32_t *host_steps, int32_t *host_diverging);
 
-/* How the last rf_env_step ran -- the three are different schedules of the same kernels with the same
- * results (tests/test_gpu_environment.py runs each against the reference's numpy glue):
+/* How the last rf_env_step ran -- different schedules of the same arithmetic with the same results
+ * (tests/test_gpu_environment.py runs each against the reference's numpy glue):
+ *   RF_ENV_BRANCH_FUSED       the default for the canonical camera: ONE render launch and one focus launch per
+ *                             step.  Which environments end depends on their counters alone, so they are ranked
+ *                             before the render, and the blocks of slots 0 .. k-1 -- whose RNG streams the k
+ *                             re-rendered frames continue (render.py:217) -- make two passes; one host
+ *                             synchronisation at any size;
+ *   RF_ENV_BRANCH_FUSED_GRAPH the same, replayed as one hipGraph from the second step on;
+ * and, with REINFOCUS_ENV_FUSED=0 (or a camera / kernel choice without a two-pass instance), two launches each:
  *   RF_ENV_BRANCH_ONE_SYNC    whole step enqueued at once, auto-reset launch sized for all n slots,
  *                             one host synchronisation (small configurations);
  *   RF_ENV_BRANCH_GRAPH       the same, replayed as one hipGraph (from such a configuration's second
@@ -269,6 +276,8 @@ int rf_env_get_counters(rf_ctx *ctx, int32_t *host_steps, int32_t *host_divergin
 #define RF_ENV_BRANCH_ONE_SYNC 1
 #define RF_ENV_BRANCH_GRAPH 2
 #define RF_ENV_BRANCH_COUNT_SIZED 3
+#define RF_ENV_BRANCH_FUSED 4
+#define RF_ENV_BRANCH_FUSED_GRAPH 5
 int rf_env_last_step_branch(rf_ctx *ctx, int *branch);
 
 /* Current states float32[n][2] (tests / checkpoint). */

@@ -419,7 +419,7 @@ class Context:
         """'none' | 'one-sync' | 'graph' | 'count-sized': how the last rf_env_step was scheduled."""
         branch = ctypes.c_int(0)
         _check(self._lib.rf_env_last_step_branch(self._h, ctypes.byref(branch)))
-        return ("none", "one-sync", "graph", "count-sized")[branch.value]
+        return ("none", "one-sync", "graph", "count-sized", "fused", "fused-graph")[branch.value]
 
     def render_kernel_name(self):
         return self._lib.rf_render_kernel_name(self._h).decode()

@@ -93,6 +93,8 @@ struct rf_ctx {
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;
     int fn = 0, fh = 0, fw = 0;
+    uint8_t *d_frames2 = nullptr; // the fused environment step: the step's frames of the environments whose slot renders twice
+    size_t frames2_cap = 0;
 
     unsigned long long *d_sums = nullptr;
     double *d_var = nullptr;
@@ -121,6 +123,8 @@ struct rf_ctx {
     bool env_graph_fail_once = false; // REINFOCUS_ENV_GRAPH_FAIL=1 (tests): the first instantiation "fails"
     int env_last_branch = RF_ENV_BRANCH_NONE; // rf_env_last_step_branch
     bool env_needs_reset = false; // rf_env_step_abort dropped a half-finished step
+    bool env_fused = true; // the step's two renders and two focus measures as one launch each (REINFOCUS_ENV_FUSED=0: the
+                           // three schedules of separate launches below)
     long env_one_sync_max = 65536; // blocks of a full render up to which rf_env_step runs without the mid-step round
                                    // trip (REINFOCUS_ENV_ONE_SYNC_MAX; tests set 0 to reach the count-sized branch at small sizes)
     const char *render_kernel = "none"; // the render kernel the last launch used (rf_render_kernel_name)
@@ -298,6 +302,20 @@ int ensure_frames(rf_ctx *ctx, int n, int h, int w)
     return RF_OK;
 }
 
+int ensure_frames2(rf_ctx *ctx, int n, int h, int w)
+{
+    const size_t need = (size_t)n * h * w * 3 + 64;
+    if (need > ctx->frames2_cap) {
+        if (ctx->d_frames2)
+            RF_HIP(hipFree(ctx->d_frames2));
+        ctx->d_frames2 = nullptr;
+        ctx->frames2_cap = 0;
+        RF_HIP(hipMalloc((void **)&ctx->d_frames2, need));
+        ctx->frames2_cap = need;
+    }
+    return RF_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -363,6 +381,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->coop = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
         ctx->two_sets = v[0] != '1';
+    if (const char *v = getenv("REINFOCUS_ENV_FUSED"))
+        ctx->env_fused = strcmp(v, "0") != 0;
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))
         ctx->env_graph_enabled = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
@@ -422,6 +442,7 @@ int rf_destroy(rf_ctx *ctx)
     if (ctx->d_cam) (void)hipFree(ctx->d_cam);
     if (ctx->d_rect) (void)hipFree(ctx->d_rect);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->d_frames2) (void)hipFree(ctx->d_frames2);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_var) (void)hipFree(ctx->d_var);
     if (ctx->env_graph) (void)hipGraphExecDestroy(ctx->env_graph);
@@ -546,13 +567,24 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
 
 namespace {
 
+// the second pass of a fused environment step's render (RenderArgs::count2 ...)
+struct SecondPass {
+    const int *count;
+    const float *cam, *rect;
+};
+
+bool fused_step_possible(const rf_ctx *ctx) { return ctx->env_fused && ctx->env_axis && ctx->coop && ctx->two_sets; }
+
 // enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
 int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, const float *rect, bool axis,
-                  bool count_pixels = true)
+                  bool count_pixels = true, const SecondPass *second = nullptr)
 {
     int rc = ensure_frames(ctx, n, h, w);
+    if (rc == RF_OK && second)
+        rc = ensure_frames2(ctx, n, h, w);
     if (rc != RF_OK)
         return rc;
+    RF_REQUIRE(!second || (axis && ctx->coop && ctx->two_sets), "launch_render: no two-pass instance of this kernel");
     rf::RenderArgs a;
     a.frames = ctx->d_frames;
     a.states = ctx->d_states;
@@ -573,6 +605,11 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     a.rh64 = 1.0 / (double)h;
     a.w64 = (double)w;
     a.h64 = (double)h;
+    a.count2 = second ? second->count : nullptr;
+    a.cam_dyn2 = second ? second->cam : nullptr;
+    a.rect2 = second ? second->rect : nullptr;
+    a.frames2 = second ? ctx->d_frames2 : nullptr;
+    a.env0 = 0;
 
     const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
     {
@@ -585,6 +622,12 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             b.cam_dyn = a.cam_dyn + (size_t)e0 * 9;
             b.rect = a.rect + (size_t)e0 * 2;
             b.n = ne;
+            if (second) {
+                b.cam_dyn2 = a.cam_dyn2 + (size_t)e0 * 9;
+                b.rect2 = a.rect2 + (size_t)e0 * 2;
+                b.frames2 = a.frames2 + (size_t)e0 * a.hw * 3;
+                b.env0 = e0;
+            }
             const dim3 grid(gx, ne), block(rf::kBlock);
             const dim3 tiles(((w + rf::kTileW - 1) / rf::kTileW) * ((h + rf::kTileH - 1) / rf::kTileH), ne);
             // A block's tile is WX waves of WW x 64/WW pixels side by side, 4/WX down, kSets sets:
@@ -600,8 +643,13 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             const bool lens32 = a.cs.lens_f32 != 0;
             if (axis && ctx->coop && ctx->two_sets) {
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
-    hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW>), tiles2, block2, 0, ctx->stream, b);         \
-    ctx->render_kernel = "render_kernel_coop2<" #P ", " #L ", " #WX ", " #WW ">"
+    if (second) {                                                                                          \
+        hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW, true>), tiles2, block2, 0, ctx->stream, b); \
+        ctx->render_kernel = "render_kernel_coop2<" #P ", " #L ", " #WX ", " #WW ", true>";                \
+    } else {                                                                                               \
+        hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW>), tiles2, block2, 0, ctx->stream, b);     \
+        ctx->render_kernel = "render_kernel_coop2<" #P ", " #L ", " #WX ", " #WW ">";                      \
+    }
 #define RF_LAUNCH2(P, L)                                                                                   \
     do {                                                                                                   \
         switch (layout) {                                                                                  \
@@ -731,7 +779,9 @@ int ensure_focus(rf_ctx *ctx, int n)
 // in_env_step: the sums were zeroed by the environment kernel before (env_pre_kernel / env_reset_kernel) and the
 // variance is taken from them by the one after (env_post_kernel / env_reset_post_kernel, the same expression as
 // focus_finalize): no memset and no finalize launch -- two nodes less per focus measure of a replayed step.
-int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr, bool in_env_step = false)
+// fused_count != null: both measures of a fused environment step as one launch of 2 n rows (FocusArgs::count2)
+int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr, bool in_env_step = false,
+                 const int *fused_count = nullptr)
 {
     // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
     const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
@@ -747,16 +797,22 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
     {
         Timed timed(ctx, &ctx->ev_focus);
         const int gx = (h + band - 1) / band;
-        for (int e0 = 0; e0 < n; e0 += 65535) {
-            const int ne = (n - e0) < 65535 ? (n - e0) : 65535;
+        const int rows = fused_count ? 2 * n : n;
+        for (int e0 = 0; e0 < rows; e0 += 65535) {
+            const int ne = (rows - e0) < 65535 ? (rows - e0) : 65535;
             rf::FocusArgs a;
-            a.frames = ctx->d_frames + (size_t)e0 * h * w * 3;
-            a.sums = ctx->d_sums + (size_t)e0 * 2;
+            a.frames = ctx->d_frames + (fused_count ? 0 : (size_t)e0 * h * w * 3);
+            a.sums = ctx->d_sums + (fused_count ? 0 : (size_t)e0 * 2);
             a.n = ne;
             a.h = h;
             a.w = w;
             a.gray15 = gray_mode == RF_GRAY_15BIT;
             a.skip_rect = skip_rect ? skip_rect + (size_t)e0 * 2 : nullptr;
+            a.count2 = fused_count;
+            a.frames2 = ctx->d_frames2;
+            a.sums2 = ctx->env.sums2;
+            a.n_step = n;
+            a.row0 = e0;
             if (quad)
                 hipLaunchKernelGGL(rf::focus_kernel_quad, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
             else
@@ -1038,7 +1094,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_state = take(n * 8), o_steps = take(n * 4), o_div = take(n * 4), o_last = take(n * 4),
                  o_oldw = take(n * 8), o_oldf = take(n * 4), o_cam = take(n * 36), o_rect = take(n * 8),
-                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_done = take(n);
+                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_done = take(n), o_sums2 = take(n * 16);
     const EnvIo io(n);
     const size_t o_io = take(io.bytes);
     RF_HIP(hipMalloc(&ctx->env_block, off));
@@ -1061,6 +1117,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     s.reward = (double *)(base + o_io + io.o_rewards);
     s.truncated = (uint8_t *)(base + o_io + io.o_truncated);
     s.done = (uint8_t *)(base + o_done);
+    s.sums2 = (unsigned long long *)(base + o_sums2);
     ctx->d_actions = (int *)(base + o_io + io.o_actions);
     ctx->d_pool = (float *)(base + o_io + io.o_pool);
 
@@ -1131,6 +1188,8 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     const dim3 grid((n + 255) / 256), block(256);
     hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env, (const int *)nullptr);
     int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis);
+    if (rc == RF_OK && fused_step_possible(ctx))
+        rc = ensure_frames2(ctx, n, fh, fh); // (not inside a step: the first one after this may already be captured)
     if (rc == RF_OK)
         rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
     if (rc != RF_OK)
@@ -1176,22 +1235,43 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
     }
     hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
                        (const int *)ctx->d_actions);
-    int rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
-    if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
-    if (rc != RF_OK)
-        return rc;
-    hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)nullptr, 0);
-    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const float *)ctx->d_pool, rf::kEnvResetBoth);
-    rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis, false);
-    if (rc == RF_OK)
-        rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2, true);
-    if (rc != RF_OK)
-        return rc;
-    hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const double *)nullptr);
+    int rc = RF_OK;
+    if (fused_step_possible(ctx)) {
+        // One render launch and one focus launch per step.  Which environments end depends on their counters alone
+        // (env_pre_kernel), so they are ranked and the compacted scene of the auto-reset is packed BEFORE the render;
+        // the r-th of them is rendered as row r of that set with the RNG streams of slot r (render.py:217), i.e. right
+        // after slot r's own frame: the blocks of the slots below the count make two passes (render_kernel_coop2<.., TWO>).
+        // The step's frames of those slots go to frames2, so that the frame buffer ends up as the two launches leave it.
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool, rf::kEnvResetPlan);
+        const SecondPass second{ctx->env.done_count, ctx->env.cam_dyn2, ctx->env.rect2};
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false, &second);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true, ctx->env.done_count);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)nullptr, 0);
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)nullptr, (const float *)ctx->d_pool);
+    } else {
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)nullptr, 0);
+        hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool, rf::kEnvResetBoth);
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis, false);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, ctx->env.rect2, true);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)nullptr, (const float *)nullptr);
+    }
     if (host_io) {
         RF_HIP(hipMemcpyAsync(host_io + io.o_rewards, d_io + io.o_rewards, io.bytes - io.o_rewards, hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -1249,7 +1329,7 @@ int env_step_end(rf_ctx *ctx, const float *host_pool, int k, float *host_obs)
         if (rc != RF_OK)
             return rc;
         hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
-                           ctx->env, (const double *)nullptr);
+                           ctx->env, (const double *)nullptr, (const float *)nullptr);
         RF_HIP(hipGetLastError());
     }
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1280,7 +1360,8 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
     // replayed as one hipGraph through pinned staging buffers; it ends with its only host
     // synchronisation.  Large ones size the auto-reset launch by the count, which costs one round
     // trip and saves up to a few hundred thousand empty blocks.
-    if (env_one_sync(ctx)) {
+    const bool fused = fused_step_possible(ctx); // (one render launch, no count to wait for: enqueued in one go at any size)
+    if (fused || env_one_sync(ctx)) {
         const EnvIo io((size_t)n);
         const size_t bytes = io.bytes;
         const bool graph = ctx->env_graph_enabled && !ctx->timing && ctx->env_steps >= 1;
@@ -1290,7 +1371,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                 return rc;
             RF_HIP(hipGetLastError());
             RF_HIP(hipStreamSynchronize(ctx->stream));
-            ctx->env_last_branch = RF_ENV_BRANCH_ONE_SYNC;
+            ctx->env_last_branch = fused ? RF_ENV_BRANCH_FUSED : RF_ENV_BRANCH_ONE_SYNC;
         } else {
             if (ctx->h_stage_bytes < bytes) {
                 if (ctx->env_graph)
@@ -1334,7 +1415,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     ctx->env_steps += 1;
                     ctx->env_scene_len = k > 0 ? k : n;
                     ctx->env_last_partial = k > 0;
-                    ctx->env_last_branch = RF_ENV_BRANCH_ONE_SYNC;
+                    ctx->env_last_branch = fused ? RF_ENV_BRANCH_FUSED : RF_ENV_BRANCH_ONE_SYNC;
                     if (host_n_reset)
                         *host_n_reset = k;
                     return RF_OK;
@@ -1348,7 +1429,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
             memcpy(host_rewards, st + io.o_rewards, (size_t)n * 8);
             memcpy(host_truncated, st + io.o_truncated, (size_t)n);
             k = *(const int *)(st + io.o_count);
-            ctx->env_last_branch = RF_ENV_BRANCH_GRAPH;
+            ctx->env_last_branch = fused ? RF_ENV_BRANCH_FUSED_GRAPH : RF_ENV_BRANCH_GRAPH;
         }
         // what this step really rendered: all n environments, then the k that ended (the other slots of the
         // second launch exit at once)
@@ -1464,7 +1545,7 @@ int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *hos
         hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
                            (const float *)ctx->d_pool, rf::kEnvResetApply);
         hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
-                           ctx->env, (const double *)ctx->d_var);
+                           ctx->env, (const double *)ctx->d_var, (const float *)nullptr);
         RF_HIP(hipGetLastError());
     }
     RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));

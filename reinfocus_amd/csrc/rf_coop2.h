@@ -363,8 +363,16 @@ __device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&
     wave_lds_order(); // (the next sample's stragglers overwrite the slots)
 }
 
-template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW>
-__global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderArgs a)
+// TWO: the environment step's render as one launch (RenderArgs::count2): the blocks of the environments below *count2
+// make two passes over their tile -- the step's frame, then the frame of the environment that takes the slot's row in the
+// auto-reset's compacted set -- instead of a second launch behind the first one's last blocks (and a host round trip for
+// its size).  Everything else is the same code: a pass ends with the pixels' states in memory, the next one reads them.
+// A pass must also COMPILE like the single-pass kernel: anything the compiler carries from one pass to the next (the
+// arguments, tile and thread geometry: all loop invariants) lives in registers through the sample loop, which has none
+// to spare (34 scalar and 19 vector registers spilled that way).  So every pass reads the arguments afresh through a
+// kernel-argument pointer and takes block and thread indices through registers the compiler cannot see through.
+template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW, bool TWO = false>
+__global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderArgs a_in)
 {
     // tile of a block: WX waves (of WW x 64 / WW pixels) side by side, 4 / WX down, kSets sets
     constexpr int tWaveW = WW, tWaveH = 64 / WW;
@@ -382,17 +390,33 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
     __shared__ float lds_colour[kColourLds][3][kBlock2];
 
-    const int e = blockIdx.y;
-    const int tid = threadIdx.x;
-    if (skip_env(a.rect, e)) // block-uniform, before any barrier
+    if (!TWO && skip_env(a_in.rect, blockIdx.y)) // block-uniform, before any barrier
         return;
+    const int passes = (TWO && a_in.env0 + (int)blockIdx.y < *a_in.count2) ? 2 : 1; // block-uniform
+    int e = blockIdx.y, block_x = blockIdx.x, tid = threadIdx.x;
+  for (int pass = 0; pass < passes; ++pass) {
+    RenderArgs a_pass;
+    if (TWO) {
+        unsigned long long kernarg = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kernarg), "+s"(e), "+s"(block_x));
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < kBlock2);
+        // (the first argument: offset 0 of the segment; constant address space: scalar loads)
+        a_pass = *(const RenderArgs *)(const __attribute__((address_space(4))) RenderArgs *)kernarg;
+    }
+    const RenderArgs &a = TWO ? a_pass : a_in;
+    const float *const scene_cam = (TWO && pass == 1) ? a.cam_dyn2 : a.cam_dyn;
+    const float *const scene_rect = (TWO && pass == 1) ? a.rect2 : a.rect;
+    uint8_t *const out_frames = (TWO && pass + 1 < passes) ? a.frames2 : a.frames;
+    if (TWO && pass != 0)
+        __syncthreads(); // (the first pass's last reads of the stage; the counters below)
     if (tid < 2)
         lds.cnt[tid] = 0;
     if (tid == 2)
         lds.cnt2 = 0;
     __syncthreads();
     const int tiles_x = (a.w + tTileW - 1) / tTileW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int tile_y = block_x / tiles_x, tile_x = block_x - tile_y * tiles_x;
     const bool mirror = (2 * tile_x + 1) * tTileW > a.w; // see render_kernel_coop
 
     // Pixel geometry of a thread.  Set j covers the rows tTileH * j further down.  All of it is
@@ -443,7 +467,18 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
             g[j] = rng_load(st.x, st.y);
         }
     }
-    PixelEnv env0 = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
+    PixelEnv env0;
+    if (TWO) { // (a pointer picked per pass is not one the compiler reads with scalar loads by itself)
+        float cam9[9], rect2[2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            cam9[i] = as_const(scene_cam + (size_t)e * 9)[i];
+        rect2[0] = as_const(scene_rect + (size_t)e * 2)[0];
+        rect2[1] = as_const(scene_rect + (size_t)e * 2)[1];
+        env0 = make_pixel_env(cam9, rect2);
+    } else {
+        env0 = make_pixel_env(scene_cam + (size_t)e * 9, scene_rect + (size_t)e * 2);
+    }
     // block-uniform values computed with vector instructions: keep them in scalar registers
     auto uniform = [](float v) { // (the builtin alone is folded away for values known to be uniform)
         int bits = __builtin_bit_cast(int, v);
@@ -579,7 +614,7 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
             sb[slot * 3 + 1] = g8;
             sb[slot * 3 + 2] = b8;
         } else if (ge.live_of(j)) {
-            uint8_t *dst = a.frames + pix_of(ge, j) * 3;
+            uint8_t *dst = out_frames + pix_of(ge, j) * 3;
             dst[0] = r8;
             dst[1] = g8;
             dst[2] = b8;
@@ -595,11 +630,12 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
             const int valid_dw = min(tTileW, a.w - tile_x * tTileW) * 3 / 4; // w % 4 == 0
             if (yy < a.h && d < valid_dw) {
                 uint32_t *dst = reinterpret_cast<uint32_t *>(
-                    a.frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * tTileW) * 3);
+                    out_frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * tTileW) * 3);
                 dst[d] = stage[r * kRowDw + d];
             }
         }
     }
+  } // pass
 }
 
 } // namespace rf

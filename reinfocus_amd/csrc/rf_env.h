@@ -55,13 +55,14 @@ struct EnvState {            // all device arrays, length n unless noted
     uint8_t *truncated;      // [n]
     uint8_t *done;           // [n] scratch
     unsigned long long *sums; // [n][2] the focus measure's (sum, sum of squares): zeroed here before a measure, read after
+    unsigned long long *sums2; // [n][2] the same for the re-rendered frames of a fused step (both measures are one launch there)
 };
 
 // ndarray.var() of a frame's Laplacian from its exact integer sums -- focus_finalize's expression (rf_kernels.h); the
 // environment kernels take the variance from the sums themselves, which saves the replayed step a launch per measure
-__device__ __forceinline__ double env_variance(const EnvConfig &c, const EnvState &s, int slot)
+__device__ __forceinline__ double env_variance(const EnvConfig &c, const unsigned long long *sums, int slot)
 {
-    const unsigned long long s1 = s.sums[2 * slot], s2 = s.sums[2 * slot + 1];
+    const unsigned long long s1 = sums[2 * slot], s2 = sums[2 * slot + 1];
     const unsigned __int128 num = (unsigned __int128)c.frame_pixels * s2 - (unsigned __int128)s1 * s1;
     const double dn = (double)c.frame_pixels;
     return (double)(unsigned long long)num / (dn * dn);
@@ -106,6 +107,12 @@ __global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
         if (diff > s.last_diff[e] + c.diverge_threshold)
             s.diverging[e] += 1;
         s.last_diff[e] = diff;
+        // which environments end is settled here already (env_post_kernel repeats it): the flags depend on the counters
+        // alone, not on what the step observes -- the fused step ranks the ended ones BEFORE its render
+        bool trunc = s.diverging[e] >= c.early_end_steps;
+        if (c.max_steps > 0)
+            trunc = (s.steps[e] >= c.max_steps) || trunc;
+        s.done[e] = trunc ? 1 : 0;
     } else { // reset of every env
         s.steps[e] = 0;
         s.diverging[e] = 0;
@@ -129,7 +136,7 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
     if (e >= c.n)
         return;
     const float target = s.state[2 * e], focus = s.state[2 * e + 1];
-    const float w0 = focus, w1 = (float)(focus_values ? focus_values[e] : env_variance(c, s, e));
+    const float w0 = focus, w1 = (float)(focus_values ? focus_values[e] : env_variance(c, s.sums, e));
     float d0 = 0.0f, d1 = 0.0f;
     if (!first) {
         d0 = w0 - s.old_wrapped[2 * e];
@@ -169,9 +176,11 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
 // environment (rf_env_step_begin / rf_env_step_end) ranks first (kEnvResetRank: done_index,
 // done_count; no pool yet -- which rows of the initializer's pool a shard takes depends on how
 // many environments ended in the shards before it) and applies later (kEnvResetApply).
-constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2;
+// kEnvResetPlan (the fused step, before its render): ranks and packs the compacted scene, but leaves the environments'
+// state alone -- env_post_kernel still has to read what the step left; env_reset_post_kernel applies it afterwards.
+constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2, kEnvResetPlan = 3;
 
-__device__ __forceinline__ void env_apply_reset(const EnvConfig &c, const EnvState &s, const float *pool, int r, int e)
+__device__ __forceinline__ void env_apply_state(const EnvState &s, const float *pool, int r, int e)
 {
     const float target = pool[2 * r], focus = pool[2 * r + 1];
     s.state[2 * e] = target;
@@ -179,7 +188,12 @@ __device__ __forceinline__ void env_apply_reset(const EnvConfig &c, const EnvSta
     s.steps[e] = 0;
     s.diverging[e] = 0;
     s.last_diff[e] = fabsf(target - focus);
-    pack_scene(c, target, focus, s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+}
+
+__device__ __forceinline__ void env_apply_reset(const EnvConfig &c, const EnvState &s, const float *pool, int r, int e)
+{
+    env_apply_state(s, pool, r, e);
+    pack_scene(c, pool[2 * r], pool[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
 }
 
 __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool, int mode)
@@ -217,6 +231,11 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
             s.done_index[r] = e;
             if (mode == kEnvResetBoth)
                 env_apply_reset(c, s, pool, r, e);
+            if (mode == kEnvResetPlan) {
+                pack_scene(c, pool[2 * r], pool[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+                s.sums2[2 * r] = 0;
+                s.sums2[2 * r + 1] = 0;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0)
@@ -248,15 +267,19 @@ __global__ void env_pack_rows_kernel(EnvConfig c, EnvState s, const float *state
 }
 
 // observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the
-// rewarder's reset (vector_environment.py:144-148)
-__global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values)
+// rewarder's reset (vector_environment.py:144-148); planned_pool != null: the fused step -- the initializer's states
+// are applied only now (kEnvResetPlan), and the re-rendered frames' sums are in sums2
+__global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values, const float *planned_pool)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= *s.done_count)
         return;
     const int e = s.done_index[r];
+    if (planned_pool)
+        env_apply_state(s, planned_pool, r, e);
     const float focus = s.state[2 * e + 1];
-    const float w0 = focus, w1 = (float)(focus_values ? focus_values[r] : env_variance(c, s, r));
+    const float w0 = focus,
+                w1 = (float)(focus_values ? focus_values[r] : env_variance(c, planned_pool ? s.sums2 : s.sums, r));
     s.old_wrapped[2 * e] = w0;
     s.old_wrapped[2 * e + 1] = w1;
     s.obs[4 * e] = normalize1(c, 0, w0);

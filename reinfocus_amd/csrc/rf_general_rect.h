@@ -39,18 +39,6 @@ struct GeneralRectArgs {
     float inv_w, inv_h;
 };
 
-// The scene arrays (cameras, shape parameters) are written by the host before the launch and never by a kernel: read
-// through the constant address space, a block-uniform address becomes an s_load into scalar registers.  (Through a plain
-// pointer the compiler has to assume that the kernel's own stores and atomics may have changed them: it then re-reads
-// them after every barrier with one vector load per lane.)
-template <class T>
-using const_as = const __attribute__((address_space(4))) T;
-template <class T>
-__device__ __forceinline__ const_as<T> *as_const(const T *p)
-{
-    return (const_as<T> *)(unsigned long long)p;
-}
-
 // camera.get_ray (camera.py:307-350): general_ray of rf_general.h with the per-environment constants from the host
 // (GeneralCamera::u64 ...: loop invariants the kernel would otherwise keep in 18 vector registers)
 __device__ __forceinline__ void general_ray_scalar(const_as<GeneralCamera> &cam, float p0, float p1, float s, float t,

@@ -31,6 +31,18 @@ __device__ __forceinline__ bool skip_env(const float *rect, int e)
     return __builtin_bit_cast(uint32_t, rect[2 * (size_t)e]) == kSkipEnvBits;
 }
 
+// The scene arrays (cameras, shape parameters) are written before the launch (by the host or by an earlier kernel) and never by the kernel that reads them: read
+// through the constant address space, a block-uniform address becomes an s_load into scalar registers.  (Through a plain
+// pointer the compiler has to assume that the kernel's own stores and atomics may have changed them: it then re-reads
+// them after every barrier with one vector load per lane.)
+template <class T>
+using const_as = const __attribute__((address_space(4))) T;
+template <class T>
+__device__ __forceinline__ const_as<T> *as_const(const T *p)
+{
+    return (const_as<T> *)(unsigned long long)p;
+}
+
 struct RenderArgs {
     uint8_t *frames;
     ulonglong2 *states;
@@ -44,6 +56,14 @@ struct RenderArgs {
     float inv_w, inv_h; // exact reciprocals when w / h are powers of two
     double rw64, rh64;  // RN64(1 / w), RN64(1 / h) for pixel_coord_div
     double w64, h64;    // (double)w, (double)h: scalar operands, no per-lane conversions
+    // render_kernel_coop2<..., TWO = true> (the environment step as one launch, rf_abi.hip enqueue_env_step_fused): the
+    // blocks of the environments below *count2 render their tile twice -- the step's frame into frames2, then the scene
+    // cam_dyn2 / rect2 of the same slot into frames, continuing the pixels' RNG streams (vector_environment.py:137-151:
+    // the r-th environment that ended is rendered again as row r of a compacted set, render.py:217)
+    const int *count2;
+    const float *cam_dyn2, *rect2;
+    uint8_t *frames2;
+    int env0; // index of the launch's first environment (launches hold at most 65535)
 };
 
 // AXIS / POW2: exact specialisations, see rf_math.h render_pixel.
@@ -416,7 +436,40 @@ struct FocusArgs {
     int n, h, w;
     int gray15; // 1: 15-bit coefficients, 0: 14-bit
     const float *skip_rect; // scene rectangles when slots may be marked kSkipEnvBits, else null
+    // both measures of a fused environment step in one launch (count2 != null; frames, sums, sums2 are then the arrays'
+    // bases and row0 the launch's first row): rows [0, n_step) are the step's frames -- frames2 for the environments
+    // below *count2, frames for the others -- into sums; rows n_step + r, r < *count2, the re-rendered frames[r] into sums2
+    const int *count2;
+    const uint8_t *frames2;
+    unsigned long long *sums2;
+    int n_step, row0;
 };
+
+// which frame a block of the focus kernels reads and where its sums go; false: nothing to do
+__device__ __forceinline__ bool focus_row(const FocusArgs &a, int row, const uint8_t *&img, unsigned long long *&sums)
+{
+    const size_t frame = (size_t)a.h * a.w * 3;
+    if (a.count2 == nullptr) {
+        if (a.skip_rect != nullptr && skip_env(a.skip_rect, row))
+            return false;
+        img = a.frames + frame * row;
+        sums = a.sums + 2 * (size_t)row;
+        return true;
+    }
+    const int count = *a.count2;
+    row += a.row0;
+    if (row < a.n_step) {
+        img = (row < count ? a.frames2 : a.frames) + frame * row;
+        sums = a.sums + 2 * (size_t)row;
+        return true;
+    }
+    row -= a.n_step;
+    if (row >= count)
+        return false;
+    img = a.frames + frame * row;
+    sums = a.sums2 + 2 * (size_t)row;
+    return true;
+}
 
 __device__ __forceinline__ uint32_t gray_of(uint32_t r, uint32_t g, uint32_t b, int gray15)
 {
@@ -447,8 +500,9 @@ __device__ __forceinline__ int reflect101(int i, int n)
 __global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int e = blockIdx.y;
-    if (a.skip_rect != nullptr && skip_env(a.skip_rect, e))
+    const uint8_t *img;
+    unsigned long long *sums;
+    if (!focus_row(a, blockIdx.y, img, sums)) // block-uniform, before any barrier
         return;
     const int r0 = blockIdx.x * kBand;               // first output row
     const int r1 = min(r0 + kBand, a.h);             // one past last output row
@@ -463,8 +517,6 @@ __global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
 
     uint8_t *gray = lds;
     uint8_t *med = lds + (size_t)(kBand + 4) * w;
-
-    const uint8_t *img = a.frames + (size_t)e * h * w * 3;
 
     const int grows = g1 - g0;
     if ((w & 3) == 0) {
@@ -533,8 +585,8 @@ __global__ __launch_bounds__(kBlock) void focus_kernel(FocusArgs a)
         s2 += __shfl_down(s2, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.sums[2 * e + 0], t1);
-        atomicAdd(&a.sums[2 * e + 1], s2);
+        atomicAdd(&sums[0], t1);
+        atomicAdd(&sums[1], s2);
     }
 }
 
@@ -555,8 +607,9 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t v, int i) { return (v >> (8
 __global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int e = blockIdx.y;
-    if (a.skip_rect != nullptr && skip_env(a.skip_rect, e))
+    const uint8_t *img;
+    unsigned long long *sums;
+    if (!focus_row(a, blockIdx.y, img, sums)) // block-uniform, before any barrier
         return;
     const int w = a.w, h = a.h, wq = a.w >> 2;
     const int r0 = blockIdx.x * kBandQ, r1 = min(r0 + kBandQ, h);
@@ -565,8 +618,6 @@ __global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
 
     uint32_t *gray = reinterpret_cast<uint32_t *>(lds);                              // [(kBandQ+4)][wq]
     uint32_t *med = reinterpret_cast<uint32_t *>(lds + (size_t)(kBandQ + 4) * w);    // [(kBandQ+2)][wq]
-    const uint8_t *img = a.frames + (size_t)e * h * w * 3;
-
     {
         const int quads = (g1 - g0) * wq;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(img + (size_t)g0 * w * 3);
@@ -654,8 +705,8 @@ __global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
         s2 += __shfl_down(s2, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.sums[2 * e + 0], t1);
-        atomicAdd(&a.sums[2 * e + 1], s2);
+        atomicAdd(&sums[0], t1);
+        atomicAdd(&sums[1], s2);
     }
 }
 

@@ -95,13 +95,19 @@ def test_vector_environment_steps_and_auto_resets(oracle):
     env.close()
 
 
-# rf_env_step has three branches (rf_abi.hip): small configurations enqueue the whole step with one
-# host synchronisation and, from their second step on, replay it as one hipGraph ("graph"); the same
-# without the graph ("one-sync"); large configurations -- the benchmarked 4096 x 256 x 256 one among
-# them -- synchronise once mid-step and size the auto-reset launch by the count ("count-sized":
-# rf_env_step_begin + rf_env_step_end).  The context reads the knobs at rf_create.
-STEP_BRANCHES = {"graph": {}, "one-sync": {"REINFOCUS_ENV_GRAPH": "0"},
-                 "count-sized": {"REINFOCUS_ENV_ONE_SYNC_MAX": "0"}}
+# rf_env_step's schedules (rf_abi.hip).  Default for the canonical camera: the step's two renders and two focus
+# measures as ONE launch each -- the environments that end are ranked before the render (the flags depend on their
+# counters alone) and the blocks of the slots whose RNG streams the re-rendered frames continue make two passes --
+# enqueued in one go ("fused") and replayed as one hipGraph from the second step on ("fused-graph").  With
+# REINFOCUS_ENV_FUSED=0 the launches are separate: small configurations enqueue the whole step with one host
+# synchronisation ("one-sync") and replay it as a graph ("graph"); large ones synchronise once mid-step and size the
+# auto-reset launch by the count ("count-sized": rf_env_step_begin + rf_env_step_end, what a sharded environment
+# uses).  The context reads the knobs at rf_create.
+STEP_BRANCHES = {"fused-graph": {}, "fused": {"REINFOCUS_ENV_GRAPH": "0"},
+                 "graph": {"REINFOCUS_ENV_FUSED": "0"},
+                 "one-sync": {"REINFOCUS_ENV_FUSED": "0", "REINFOCUS_ENV_GRAPH": "0"},
+                 "count-sized": {"REINFOCUS_ENV_FUSED": "0", "REINFOCUS_ENV_ONE_SYNC_MAX": "0"}}
+FIRST_STEP_BRANCH = {"fused-graph": "fused", "graph": "one-sync"}  # (a graph is captured from the second step on)
 
 
 @pytest.mark.parametrize("branch", list(STEP_BRANCHES))
@@ -136,7 +142,7 @@ def test_device_resident_step_equals_host_harness(n, height, spp, steps, branch,
         assert np.array_equal(host._state, dev._state)
         resets += int(ch.sum())
         # (a graph is captured from the second step on, when every buffer has its final size)
-        assert dev._ctx.env_last_step_branch() == ("one-sync" if branch == "graph" and step == 0 else branch)
+        assert dev._ctx.env_last_step_branch() == (FIRST_STEP_BRANCH.get(branch, branch) if step == 0 else branch)
     assert resets > 0
     # both initializers consumed the same number of draws
     assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state

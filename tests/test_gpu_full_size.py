@@ -148,11 +148,13 @@ def test_first_hip_config(native, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,h,spp,branch", [(4096, 256, 16, "count-sized"), (128, 512, 64, "graph")])
-def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, branch):
+@pytest.mark.parametrize("n,h,spp,branch", [(4096, 256, 16, "fused-graph"), (4096, 256, 16, "count-sized"),
+                                            (128, 512, 64, "fused-graph"), (128, 512, 64, "graph")])
+def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, branch, monkeypatch):
     """The object bench.py measures, at the sizes it is measured at (BASELINE configs[2] and the
     per-GPU share of configs[4]): harness.DeviceVectorDiscreteSteps -- whose rf_env_step takes the
-    count-sized branch at the headline size (rf_env_step_begin, one host round trip,
+    fused schedule (one render launch whose blocks of the re-rendered slots make two passes), and with
+    REINFOCUS_ENV_FUSED=0 the count-sized branch at the headline size (rf_env_step_begin, one host round trip,
     rf_env_step_end; 128 environments of 512 x 512 are few enough blocks for the one-sync / hipGraph
     schedule) -- against harness.VectorDiscreteSteps, the reference's numpy glue
     (environments/vector_environment.py:104-164) around rf_render / rf_focus, which the tests above
@@ -165,7 +167,10 @@ def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, bra
 
     kw = dict(max_episode_steps=4, num_envs=n, frame_height=h, samples_per_pixel=spp, seed=3, device=0)
     host = harness.VectorDiscreteSteps(**kw)
+    if not branch.startswith("fused"):
+        monkeypatch.setenv("REINFOCUS_ENV_FUSED", "0")
     dev = harness.DeviceVectorDiscreteSteps(**kw)
+    monkeypatch.delenv("REINFOCUS_ENV_FUSED", raising=False)
     o_h, _ = host.reset()
     o_d, _ = dev.reset()
     assert np.array_equal(o_h, o_d) and np.array_equal(host._state, dev._state)
@@ -174,7 +179,8 @@ def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, bra
     for step in range(7):
         actions = rng.integers(0, 13, n)
         want, got = host.step(actions), dev.step(actions)
-        assert dev._ctx.env_last_step_branch() == ("one-sync" if branch == "graph" and step == 0 else branch)
+        first = {"graph": "one-sync", "fused-graph": "fused"}.get(branch, branch)
+        assert dev._ctx.env_last_step_branch() == (first if step == 0 else branch)
         for a, b in zip(want[:4], got[:4]):
             assert a.dtype == b.dtype and np.array_equal(a, b)
         assert np.array_equal(host._state, dev._state)
