@@ -1094,7 +1094,8 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_state = take(n * 8), o_steps = take(n * 4), o_div = take(n * 4), o_last = take(n * 4),
                  o_oldw = take(n * 8), o_oldf = take(n * 4), o_cam = take(n * 36), o_rect = take(n * 8),
-                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_done = take(n), o_sums2 = take(n * 16);
+                 o_cam2 = take(n * 36), o_rect2 = take(n * 8), o_didx = take(n * 4), o_done = take(n), o_sums2 = take(n * 16),
+                 o_drank = take(n * 4);
     const EnvIo io(n);
     const size_t o_io = take(io.bytes);
     RF_HIP(hipMalloc(&ctx->env_block, off));
@@ -1118,6 +1119,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
     s.truncated = (uint8_t *)(base + o_io + io.o_truncated);
     s.done = (uint8_t *)(base + o_done);
     s.sums2 = (unsigned long long *)(base + o_sums2);
+    s.done_rank = (int *)(base + o_drank);
     ctx->d_actions = (int *)(base + o_io + io.o_actions);
     ctx->d_pool = (float *)(base + o_io + io.o_pool);
 
@@ -1233,8 +1235,6 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
         RF_HIP(hipMemcpyAsync(ctx->d_actions, actions, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         RF_HIP(hipMemcpyAsync(ctx->d_pool, pool, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                       (const int *)ctx->d_actions);
     int rc = RF_OK;
     if (fused_step_possible(ctx)) {
         // One render launch and one focus launch per step.  Which environments end depends on their counters alone
@@ -1243,18 +1243,18 @@ int enqueue_env_step(rf_ctx *ctx, const int32_t *actions, const float *pool, flo
         // after slot r's own frame: the blocks of the slots below the count make two passes (render_kernel_coop2<.., TWO>).
         // The step's frames of those slots go to frames2, so that the frame buffer ends up as the two launches leave it.
         hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const float *)ctx->d_pool, rf::kEnvResetPlan);
+                           (const float *)ctx->d_pool, rf::kEnvResetPlan, (const int *)ctx->d_actions);
         const SecondPass second{ctx->env.done_count, ctx->env.cam_dyn2, ctx->env.rect2};
         rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false, &second);
         if (rc == RF_OK)
             rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true, ctx->env.done_count);
         if (rc != RF_OK)
             return rc;
-        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const double *)nullptr, 0);
-        hipLaunchKernelGGL(rf::env_reset_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
-                           (const double *)nullptr, (const float *)ctx->d_pool);
+        hipLaunchKernelGGL(rf::env_finish_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool);
     } else {
+        hipLaunchKernelGGL(rf::env_pre_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const int *)ctx->d_actions);
         rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
         if (rc == RF_OK)
             rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);

@@ -49,6 +49,7 @@ struct EnvState {            // all device arrays, length n unless noted
     float *cam_dyn, *rect;   // scene of all n envs
     float *cam_dyn2, *rect2; // compacted scene of the envs that reset this step
     int *done_index;         // [n] env index of the r-th reset env
+    int *done_rank;          // [n] the inverse for the envs that ended (fused step)
     int *done_count;         // [1]
     float *obs;              // [n][4]
     double *reward;          // [n]
@@ -89,11 +90,8 @@ __device__ __forceinline__ void pack_scene(const EnvConfig &c, float target, flo
 
 // transformer -> ender.step -> scene of every env (vector_environment.py:124-126 + the
 // update_targets / update_focus_planes of FocusObserver.observe)
-__global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
+__device__ __forceinline__ void env_pre_one(const EnvConfig &c, const EnvState &s, const int *actions, int e)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= c.n)
-        return;
     float target = s.state[2 * e], focus = s.state[2 * e + 1];
     if (actions) { // step: new = clip(f32(f64(old) + move), lo, hi) on BOTH columns
         focus = (float)((double)focus + c.action_set[actions[e]]);
@@ -123,6 +121,13 @@ __global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
     s.sums[2 * e + 1] = 0;
 }
 
+__global__ void env_pre_kernel(EnvConfig c, EnvState s, const int *actions)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < c.n)
+        env_pre_one(c, s, actions, e);
+}
+
 __device__ __forceinline__ float normalize1(const EnvConfig &c, int k, float v)
 {
     return fminf(fmaxf((v - c.mid[k]) / c.scale[k], -1.0f), 1.0f);
@@ -130,11 +135,8 @@ __device__ __forceinline__ float normalize1(const EnvConfig &c, int k, float v)
 
 // observe -> reward -> done flags (vector_environment.py:128-135); `first` = reset() call
 // focus_values == nullptr: the variance comes from the sums the focus kernel left (env_variance)
-__global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_values, int first)
+__device__ __forceinline__ void env_post_one(const EnvConfig &c, const EnvState &s, const double *focus_values, int first, int e)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= c.n)
-        return;
     const float target = s.state[2 * e], focus = s.state[2 * e + 1];
     const float w0 = focus, w1 = (float)(focus_values ? focus_values[e] : env_variance(c, s.sums, e));
     float d0 = 0.0f, d1 = 0.0f;
@@ -169,6 +171,13 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
     s.done[e] = trunc ? 1 : 0;
 }
 
+__global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_values, int first)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < c.n)
+        env_post_one(c, s, focus_values, first, e);
+}
+
 // Ranks the done envs in index order (single block, running offset) and applies the
 // initializer's r-th candidate state to the r-th done env (vector_environment.py:138-142),
 // resets its enders, and packs the compacted scene of the partial render.
@@ -176,8 +185,9 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
 // environment (rf_env_step_begin / rf_env_step_end) ranks first (kEnvResetRank: done_index,
 // done_count; no pool yet -- which rows of the initializer's pool a shard takes depends on how
 // many environments ended in the shards before it) and applies later (kEnvResetApply).
-// kEnvResetPlan (the fused step, before its render): ranks and packs the compacted scene, but leaves the environments'
-// state alone -- env_post_kernel still has to read what the step left; env_reset_post_kernel applies it afterwards.
+// kEnvResetPlan (the fused step, before its render): the work of env_pre_kernel first (`actions`), then ranks and packs
+// the compacted scene, but leaves the environments' state alone -- the step's observations and rewards still have to be
+// taken from what the step left; env_finish_kernel applies the initializer's states afterwards.
 constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2, kEnvResetPlan = 3;
 
 __device__ __forceinline__ void env_apply_state(const EnvState &s, const float *pool, int r, int e)
@@ -196,7 +206,8 @@ __device__ __forceinline__ void env_apply_reset(const EnvConfig &c, const EnvSta
     pack_scene(c, pool[2 * r], pool[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
 }
 
-__global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool, int mode)
+__global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s, const float *pool, int mode,
+                                                         const int *actions = nullptr)
 {
     __shared__ int wave_sum[16];
     __shared__ int running;
@@ -214,6 +225,8 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
     __syncthreads();
     for (int base = 0; base < c.n; base += 1024) {
         const int e = base + threadIdx.x;
+        if (mode == kEnvResetPlan && e < c.n)
+            env_pre_one(c, s, actions, e); // (sets done[e], read by the same thread below)
         const bool d = e < c.n && s.done[e];
         const unsigned long long ballot = __ballot(d);
         const int lane_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32),
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
             if (mode == kEnvResetBoth)
                 env_apply_reset(c, s, pool, r, e);
             if (mode == kEnvResetPlan) {
+                s.done_rank[e] = r;
                 pack_scene(c, pool[2 * r], pool[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
                 s.sums2[2 * r] = 0;
                 s.sums2[2 * r + 1] = 0;
@@ -269,12 +283,9 @@ __global__ void env_pack_rows_kernel(EnvConfig c, EnvState s, const float *state
 // observations of the freshly reset envs (DeltaObserver.reset: zero deltas) and the
 // rewarder's reset (vector_environment.py:144-148); planned_pool != null: the fused step -- the initializer's states
 // are applied only now (kEnvResetPlan), and the re-rendered frames' sums are in sums2
-__global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values, const float *planned_pool)
+__device__ __forceinline__ void env_reset_post_one(const EnvConfig &c, const EnvState &s, const double *focus_values,
+                                                   const float *planned_pool, int r, int e)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *s.done_count)
-        return;
-    const int e = s.done_index[r];
     if (planned_pool)
         env_apply_state(s, planned_pool, r, e);
     const float focus = s.state[2 * e + 1];
@@ -287,6 +298,24 @@ __global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *foc
     s.obs[4 * e + 2] = normalize1(c, 2, 0.0f);
     s.obs[4 * e + 3] = normalize1(c, 3, 0.0f);
     s.old_focus[e] = focus;
+}
+
+__global__ void env_reset_post_kernel(EnvConfig c, EnvState s, const double *focus_values, const float *planned_pool)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < *s.done_count)
+        env_reset_post_one(c, s, focus_values, planned_pool, r, s.done_index[r]);
+}
+
+// the fused step's last kernel: env_post_kernel and env_reset_post_kernel as one launch (both measures are done by then)
+__global__ void env_finish_kernel(EnvConfig c, EnvState s, const float *planned_pool)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.n)
+        return;
+    env_post_one(c, s, nullptr, 0, e);
+    if (s.done[e])
+        env_reset_post_one(c, s, nullptr, planned_pool, s.done_rank[e], e);
 }
 
 } // namespace rf
