@@ -224,6 +224,19 @@ int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rew
 int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs);
 int rf_env_step_abort(rf_ctx *ctx);
 
+/* The two halves a sharded environment uses by default (harness.ShardedVectorDiscreteSteps), cut where the fused
+ * step (RF_ENV_BRANCH_FUSED below) allows -- BEFORE the render, because which environments end depends on their
+ * counters alone (episode_ender.py:137-148, :602-607), not on what the step observes:
+ *   rf_env_step_plan    transform + enders + ranking of the environments that end; *host_n_reset = k.  Cheap: no render.
+ *   rf_env_step_run     the rest of the step with host_pool float32[k][2] for those k (NULL when k == 0): ONE render
+ *                       launch (two-pass blocks for slots 0 .. k-1) and one focus launch where the two-pass kernel
+ *                       exists, the separate launches of rf_env_step_begin / _end otherwise -- same results either way,
+ *                       and the same as begin + end.  Outputs as rf_env_step.
+ * rf_env_step_abort drops a planned step as it drops a begun one.  No reference counterpart
+ * (vector_environment.py:104-164 is one synchronous schedule on one device). */
+int rf_env_step_plan(rf_ctx *ctx, const int32_t *host_actions, int *host_n_reset);
+int rf_env_step_run(rf_ctx *ctx, const float *host_pool, float *host_obs, double *host_rewards, uint8_t *host_truncated);
+
 /* Exact mode of an environment sharded over several contexts (opt-in; harness.ShardedVectorDiscreteSteps
  * exact=True).  On one device the partial render of an auto-reset indexes RNG states from 0 over the
  * compacted rows of ALL environments that ended (vector_environment.py:144 -> state_observer.py:377-381

@@ -52,6 +52,8 @@ SYMBOLS = (
     "rf_env_step_begin",
     "rf_env_step_end",
     "rf_env_step_abort",
+    "rf_env_step_plan",
+    "rf_env_step_run",
     "rf_env_render_states",
     "rf_env_step_end_given",
     "rf_env_get_states",
@@ -142,6 +144,8 @@ def load():
     lib.rf_env_step_begin.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
     lib.rf_env_step_end.argtypes = [vp, vp, vp]
     lib.rf_env_step_abort.argtypes = [vp]
+    lib.rf_env_step_plan.argtypes = [vp, vp, ctypes.POINTER(i32)]
+    lib.rf_env_step_run.argtypes = [vp, vp, vp, vp, vp]
     lib.rf_env_render_states.argtypes = [vp, i32, vp, vp]
     lib.rf_env_step_end_given.argtypes = [vp, vp, vp, vp]
     lib.rf_env_get_states.argtypes = [vp, vp]
@@ -373,6 +377,25 @@ class Context:
         obs = np.empty((n, 4), dtype=np.float32)
         _check(self._lib.rf_env_step_end(self._h, _ptr(pool_rows) if len(pool_rows) else None, _ptr(obs)))
         return obs
+
+    def env_step_plan(self, actions):
+        """First half of a step cut BEFORE its render (transform, enders, ranking): how many environments end."""
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self._env_n)
+        k = ctypes.c_int(0)
+        _check(self._lib.rf_env_step_plan(self._h, _ptr(actions), ctypes.byref(k)))
+        return k.value
+
+    def env_step_run(self, pool_rows):
+        """The rest of a planned step with pool_rows float32[k, 2] for the environments that end:
+        (observations, rewards, truncated)."""
+        n = self._env_n
+        pool_rows = np.ascontiguousarray(pool_rows, dtype=np.float32).reshape(-1, 2)
+        obs = np.empty((n, 4), dtype=np.float32)
+        rewards = np.empty(n, dtype=np.float64)
+        truncated = np.empty(n, dtype=np.uint8)
+        _check(self._lib.rf_env_step_run(self._h, _ptr(pool_rows) if len(pool_rows) else None, _ptr(obs), _ptr(rewards),
+                                         _ptr(truncated)))
+        return obs, rewards, truncated.astype(bool)
 
     def env_render_states(self, states):
         """Exact mode of a sharded environment: float32[k, 2] states rendered and scored as compacted rows

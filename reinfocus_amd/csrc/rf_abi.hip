@@ -120,6 +120,7 @@ struct rf_ctx {
     bool env_last_partial = false; // that set is the compacted one of an auto-reset (cam_dyn2 / rect2)
     int env_scene_len = 0; // environments of the scene set uploaded last: n after a full render, k after a partial one
     int env_pending = -1; // >= 0: rf_env_step_begin ran and that many environments wait for rf_env_step_end
+    bool env_planned = false; // the open step is rf_env_step_plan's (rf_env_step_run finishes it)
     bool env_graph_fail_once = false; // REINFOCUS_ENV_GRAPH_FAIL=1 (tests): the first instantiation "fails"
     int env_last_branch = RF_ENV_BRANCH_NONE; // rf_env_last_step_branch
     bool env_needs_reset = false; // rf_env_step_abort dropped a half-finished step
@@ -1173,6 +1174,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
                     !signbit(cfg->cam_v[2]) && cfg->half_width > 0.0 && cfg->half_height > 0.0;
     ctx->scene_n = 0; // the env owns the scene arrays from now on
     ctx->env_pending = -1;
+    ctx->env_planned = false;
     ctx->env_ready = true;
     return RF_OK;
 }
@@ -1183,6 +1185,7 @@ int rf_env_reset(rf_ctx *ctx, const float *host_states, float *host_obs)
     RF_REQUIRE(ctx->env_ready, "rf_env_reset: rf_env_configure first");
     RF_HIP(hipSetDevice(ctx->device));
     ctx->env_pending = -1;
+    ctx->env_planned = false;
     ctx->env_needs_reset = false;
     const rf_env_config &h = ctx->env_host;
     const int n = h.n, fh = h.frame_height;
@@ -1484,7 +1487,7 @@ int rf_env_step_begin(rf_ctx *ctx, const int32_t *host_actions, double *host_rew
 int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs)
 {
     RF_REQUIRE(ctx != nullptr && host_obs != nullptr, "rf_env_step_end: NULL argument");
-    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0, "rf_env_step_end: rf_env_step_begin first");
+    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0 && !ctx->env_planned, "rf_env_step_end: rf_env_step_begin first");
     RF_REQUIRE(ctx->env_pending == 0 || host_pool != nullptr, "rf_env_step_end: %d environments ended but host_pool is NULL",
                ctx->env_pending);
     RF_HIP(hipSetDevice(ctx->device));
@@ -1499,6 +1502,93 @@ int rf_env_step_end(rf_ctx *ctx, const float *host_pool, float *host_obs)
         ctx->env_needs_reset = true; // the second half failed part way: only a reset makes the environment usable again
     }
     return rc;
+}
+
+int rf_env_step_plan(rf_ctx *ctx, const int32_t *host_actions, int *host_n_reset)
+{
+    RF_REQUIRE(ctx != nullptr && host_actions && host_n_reset, "rf_env_step_plan: NULL argument");
+    RF_REQUIRE(ctx->env_ready, "rf_env_step_plan: rf_env_configure first");
+    RF_REQUIRE(ctx->env_pending < 0, "rf_env_step_plan: the previous step was not finished");
+    RF_REQUIRE(!ctx->env_needs_reset, "rf_env_step_plan: a step was aborted (rf_env_reset first)");
+    RF_HIP(hipSetDevice(ctx->device));
+    drop_env_graph(ctx);
+    const rf_env_config &h = ctx->env_host;
+    for (int i = 0; i < h.n; ++i)
+        RF_REQUIRE(host_actions[i] >= 0 && host_actions[i] < h.n_actions,
+                   "rf_env_step_plan: action %d of env %d out of range", host_actions[i], i);
+    RF_HIP(hipMemcpyAsync(ctx->d_actions, host_actions, (size_t)h.n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                       (const float *)nullptr, rf::kEnvResetRank, (const int *)ctx->d_actions);
+    RF_HIP(hipGetLastError());
+    int k = 0;
+    RF_HIP(hipMemcpyAsync(&k, ctx->env.done_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->env_pending = k;
+    ctx->env_planned = true;
+    *host_n_reset = k;
+    return RF_OK;
+}
+
+int rf_env_step_run(rf_ctx *ctx, const float *host_pool, float *host_obs, double *host_rewards, uint8_t *host_truncated)
+{
+    RF_REQUIRE(ctx != nullptr && host_obs && host_rewards && host_truncated, "rf_env_step_run: NULL argument");
+    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0 && ctx->env_planned, "rf_env_step_run: rf_env_step_plan first");
+    RF_REQUIRE(ctx->env_pending == 0 || host_pool != nullptr, "rf_env_step_run: %d environments ended but host_pool is NULL",
+               ctx->env_pending);
+    RF_HIP(hipSetDevice(ctx->device));
+    const int k = ctx->env_pending;
+    ctx->env_pending = -1;
+    ctx->env_planned = false;
+    ctx->env_needs_reset = true; // until the step has finished (a failure below returns early)
+    const rf_env_config &h = ctx->env_host;
+    const int n = h.n, fh = h.frame_height;
+    const dim3 grid((n + 255) / 256), block(256);
+    int rc = RF_OK;
+    if (k > 0)
+        RF_HIP(hipMemcpyAsync(ctx->d_pool, host_pool, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (fused_step_possible(ctx)) {
+        if (k > 0)
+            hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                               (const float *)ctx->d_pool, rf::kEnvResetPack, (const int *)nullptr);
+        const SecondPass second{ctx->env.done_count, ctx->env.cam_dyn2, ctx->env.rect2};
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false, &second);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true, ctx->env.done_count);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_finish_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const float *)ctx->d_pool);
+    } else {
+        rc = launch_render(ctx, n, fh, fh, h.spp, ctx->env.cam_dyn, ctx->env.rect, ctx->env_axis, false);
+        if (rc == RF_OK)
+            rc = launch_focus(ctx, n, fh, fh, h.gray_mode, nullptr, true);
+        if (rc != RF_OK)
+            return rc;
+        hipLaunchKernelGGL(rf::env_post_kernel, grid, block, 0, ctx->stream, ctx->env_cfg, ctx->env,
+                           (const double *)nullptr, 0);
+        if (k > 0) {
+            hipLaunchKernelGGL(rf::env_reset_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->env_cfg, ctx->env,
+                               (const float *)ctx->d_pool, rf::kEnvResetApply, (const int *)nullptr);
+            rc = launch_render(ctx, k, fh, fh, h.spp, ctx->env.cam_dyn2, ctx->env.rect2, ctx->env_axis, false);
+            if (rc == RF_OK)
+                rc = launch_focus(ctx, k, fh, fh, h.gray_mode, nullptr, true);
+            if (rc != RF_OK)
+                return rc;
+            hipLaunchKernelGGL(rf::env_reset_post_kernel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, ctx->env_cfg,
+                               ctx->env, (const double *)nullptr, (const float *)nullptr);
+        }
+    }
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(host_rewards, ctx->env.reward, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_truncated, ctx->env.truncated, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipMemcpyAsync(host_obs, ctx->env.obs, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RF_HIP(hipStreamSynchronize(ctx->stream));
+    g_pixels_rendered += (unsigned long long)(n + k) * (unsigned long long)fh * fh;
+    ctx->env_needs_reset = false;
+    ctx->env_steps += 1;
+    ctx->env_scene_len = k > 0 ? k : n;
+    ctx->env_last_partial = k > 0;
+    return RF_OK;
 }
 
 int rf_env_render_states(rf_ctx *ctx, int k, const float *host_states, double *host_focus)
@@ -1529,7 +1619,7 @@ int rf_env_render_states(rf_ctx *ctx, int k, const float *host_states, double *h
 int rf_env_step_end_given(rf_ctx *ctx, const float *host_pool, const double *host_focus, float *host_obs)
 {
     RF_REQUIRE(ctx != nullptr && host_obs != nullptr, "rf_env_step_end_given: NULL argument");
-    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0, "rf_env_step_end_given: rf_env_step_begin first");
+    RF_REQUIRE(ctx->env_ready && ctx->env_pending >= 0 && !ctx->env_planned, "rf_env_step_end_given: rf_env_step_begin first");
     const int k = ctx->env_pending;
     RF_REQUIRE(k == 0 || (host_pool != nullptr && host_focus != nullptr),
                "rf_env_step_end_given: %d environments ended but host_pool / host_focus is NULL", k);
@@ -1563,6 +1653,7 @@ int rf_env_step_abort(rf_ctx *ctx)
         // the episode bookkeeping of the environments that ended is half way through a step: only a
         // reset makes the environment usable again, and rf_env_step / _begin say so until then
         ctx->env_pending = -1;
+        ctx->env_planned = false;
         ctx->env_needs_reset = true;
     }
     return RF_OK;

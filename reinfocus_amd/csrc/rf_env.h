@@ -188,7 +188,9 @@ __global__ void env_post_kernel(EnvConfig c, EnvState s, const double *focus_val
 // kEnvResetPlan (the fused step, before its render): the work of env_pre_kernel first (`actions`), then ranks and packs
 // the compacted scene, but leaves the environments' state alone -- the step's observations and rewards still have to be
 // taken from what the step left; env_finish_kernel applies the initializer's states afterwards.
-constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2, kEnvResetPlan = 3;
+// kEnvResetPack: kEnvResetPlan's packing half for a ranking that exists already (rf_env_step_plan / rf_env_step_run).
+// `actions` != null in a ranking mode: the transformer / ender work of env_pre_kernel first.
+constexpr int kEnvResetBoth = 0, kEnvResetRank = 1, kEnvResetApply = 2, kEnvResetPlan = 3, kEnvResetPack = 4;
 
 __device__ __forceinline__ void env_apply_state(const EnvState &s, const float *pool, int r, int e)
 {
@@ -220,12 +222,22 @@ __global__ __launch_bounds__(1024) void env_reset_kernel(EnvConfig c, EnvState s
         }
         return;
     }
+    if (mode == kEnvResetPack) {
+        const int count = *s.done_count;
+        for (int r = (int)threadIdx.x; r < count; r += 1024) {
+            s.done_rank[s.done_index[r]] = r;
+            pack_scene(c, pool[2 * r], pool[2 * r + 1], s.cam_dyn2 + 9 * r, s.rect2 + 2 * r);
+            s.sums2[2 * r] = 0;
+            s.sums2[2 * r + 1] = 0;
+        }
+        return;
+    }
     if (threadIdx.x == 0)
         running = 0;
     __syncthreads();
     for (int base = 0; base < c.n; base += 1024) {
         const int e = base + threadIdx.x;
-        if (mode == kEnvResetPlan && e < c.n)
+        if (actions != nullptr && e < c.n)
             env_pre_one(c, s, actions, e); // (sets done[e], read by the same thread below)
         const bool d = e < c.n && s.done[e];
         const unsigned long long ballot = __ballot(d);

@@ -585,8 +585,10 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
     (pixel index = e * h * w + y * w + x, render.py:217), so full renders draw exactly what one
     device holding all environments would draw.  Initializer: one generator for the whole
     environment; the r-th environment that ended, in global index order, takes the r-th drawn
-    state, as on one device -- which is why a step has two halves (rf_env_step_begin /
-    rf_env_step_end): the rows a shard takes depend on how many environments ended before it.
+    state, as on one device -- which is why a step has two halves: the rows a shard takes depend on
+    how many environments ended before it.  The cut is before the render (rf_env_step_plan /
+    rf_env_step_run: which environments end depends on their counters alone), so the first half is
+    cheap and the second is the fused step -- one render launch per shard.
 
     Auto-reset renders.  On one device the partial render indexes RNG states from 0 over the
     compacted rows of all environments that ended (vector_environment.py:144 -> render.py:217):
@@ -726,9 +728,14 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         return observations, {}
 
     def _begin(self, actions):
-        """First half of the step on every shard.  If any shard fails, the shards whose half did run
+        """First half of the step on every shard -- rf_env_step_plan (transform, enders, ranking: the cut before the
+        render that lets the second half run as ONE render launch), in the exact mode rf_env_step_begin (the cut after
+        the full render: its row renders happen on other shards).  If any shard fails, the shards whose half did run
         drop it (rf_env_step_abort: they then insist on a reset) and the first error is raised."""
-        futures = self._submit(lambda shard, a: shard.ctx.env_step_begin(a), self._slices(actions))
+        if self.exact:
+            futures = self._submit(lambda shard, a: shard.ctx.env_step_begin(a), self._slices(actions))
+        else:
+            futures = self._submit(lambda shard, a: (None, None, shard.ctx.env_step_plan(a)), self._slices(actions))
         results, errors = [], []
         for future in futures:
             try:
@@ -772,7 +779,9 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
                 observations = self._results(self._submit(lambda shard, r: shard.ctx.env_step_end_given(r, np.zeros(0)),
                                                           rows))
             else:
-                observations = self._results(self._submit(lambda shard, r: shard.ctx.env_step_end(r), rows))
+                finished = self._results(self._submit(lambda shard, r: shard.ctx.env_step_run(r), rows))
+                observations = [o for o, _, _ in finished]
+                firsts = [(r, t, k) for (_, r, t), (_, _, k) in zip(finished, firsts)]
         except Exception:
             # some shard failed in the second half: the others must not keep a half-finished step (those that had
             # finished theirs refuse the abort, which is fine) -- every shard then insists on a reset or was done

@@ -498,6 +498,57 @@ def test_two_phase_step_guards():
     env.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_planned_step_equals_the_whole_step(fused, monkeypatch):
+    """rf_env_step_plan + rf_env_step_run (the halves a sharded environment uses: the cut is before the render) against
+    rf_env_step with the same pool, through auto-resets, with and without the two-pass render kernel; and the guards:
+    a planned step is finished by rf_env_step_run only."""
+    from reinfocus_amd.environments import harness
+
+    n = 96
+    kw = dict(max_episode_steps=5, num_envs=n, frame_height=32, samples_per_pixel=3, seed=19, device=0)
+    monkeypatch.setenv("REINFOCUS_ENV_FUSED", fused)
+    whole, halves = harness.DeviceVectorDiscreteSteps(**kw), harness.DeviceVectorDiscreteSteps(**kw)
+    monkeypatch.delenv("REINFOCUS_ENV_FUSED")
+    assert np.array_equal(whole.reset()[0], halves.reset()[0])
+    rng = np.random.default_rng(2)
+    pools = np.random.default_rng(77)
+    ended = 0
+    for step in range(14):
+        actions = rng.integers(0, 13, n)
+        pool = pools.uniform(5, 10, size=(n, 2)).astype(np.float32)
+        obs, rewards, truncated, used = whole._ctx.env_step(actions, pool)
+        k = halves._ctx.env_step_plan(actions)
+        assert k == used
+        if step == 3:
+            with pytest.raises(AssertionError):
+                halves._ctx.env_step(actions, pool)
+            with pytest.raises(AssertionError):
+                halves._ctx.env_step_end(pool[:k])
+            with pytest.raises(AssertionError):
+                halves._ctx.env_step_plan(actions)
+        got = halves._ctx.env_step_run(pool[:k])
+        assert np.array_equal(got[0], obs) and np.array_equal(got[1], rewards) and np.array_equal(got[2], truncated)
+        assert np.array_equal(whole._state, halves._state)
+        assert halves._ctx.env_scene_len() == (k or n)
+        ended += k
+    assert ended > n
+    assert np.array_equal(whole._ctx.get_states(), halves._ctx.get_states())
+    rows = k or n  # (the frame buffer's leading rows hold the scene set rendered last on every schedule)
+    frames = [env._ctx.get_frames((n, 32, 32), 0, rows) for env in (whole, halves)]
+    assert np.array_equal(*frames)
+    with pytest.raises(AssertionError):
+        halves._ctx.env_step_run(np.zeros((0, 2), dtype=np.float32))
+    halves._ctx.env_step_plan(rng.integers(0, 13, n))
+    halves._ctx.env_step_abort()
+    with pytest.raises(AssertionError):
+        halves._ctx.env_step_plan(rng.integers(0, 13, n))  # (a dropped step: reset first)
+    halves.reset()
+    halves.step(rng.integers(0, 13, n))
+    whole.close()
+    halves.close()
+
+
 def test_env_step_graph_capture_failure_falls_back(monkeypatch):
     """rf_env_step's hipGraph branch when instantiation fails (REINFOCUS_ENV_GRAPH_FAIL=1 makes the
     first one fail): the step is enqueued call by call from then on, with identical results."""

@@ -195,6 +195,38 @@ def test_benchmarked_environment_equals_host_harness_at_full_size(n, h, spp, bra
     dev.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_environment_step_beyond_one_launch(fused, monkeypatch):
+    """More environments than one launch holds (65 535 rows of blocks): the fused step's render is then several
+    launches whose two-pass test needs the launch's first environment (RenderArgs::env0), and its focus launch of
+    2 n rows several more (FocusArgs::row0); the count of environments that end crosses the launch boundary in
+    step 4 (everybody ends: time limit).  Against the numpy glue around rf_render / rf_focus, bit for bit."""
+    from reinfocus_amd.environments import harness
+
+    n, h = 65600, 16
+    kw = dict(max_episode_steps=4, num_envs=n, frame_height=h, samples_per_pixel=1, seed=8, device=0)
+    host = harness.VectorDiscreteSteps(**kw)
+    monkeypatch.setenv("REINFOCUS_ENV_FUSED", fused)
+    dev = harness.DeviceVectorDiscreteSteps(**kw)
+    monkeypatch.delenv("REINFOCUS_ENV_FUSED")
+    assert np.array_equal(host.reset()[0], dev.reset()[0])
+    rng = np.random.default_rng(23)
+    ended = []
+    for _step in range(6):
+        actions = rng.integers(0, 13, n)
+        want, got = host.step(actions), dev.step(actions)
+        for a, b in zip(want[:4], got[:4]):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert np.array_equal(host._state, dev._state)
+        ended.append(int(got[3].sum()))
+    assert dev._ctx.env_last_step_branch() == ("fused-graph" if fused == "1" else "count-sized")
+    assert 0 < ended[2] < n and ended[2] + ended[3] == n and 0 < ended[5] < n
+    for first in (0, 65535 * h * h, (n - 1) * h * h):
+        assert np.array_equal(host._renderer._ctx.get_states(first, h * h), dev._ctx.get_states(first, h * h))
+    host.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("n,h,spp,shards", [(32768, 256, 16, 8), (1024, 512, 64, 8)])
 def test_whole_multi_gpu_configuration_on_eight_contexts(n, h, spp, shards):
     """BASELINE configs[3] (32768 envs x 256 x 256 x 16 spp) and configs[4] (1024 envs x 512 x 512 x 64

@@ -1,7 +1,7 @@
 """Host logic of harness.ShardedVectorDiscreteSteps and of the gymnasium base classes, on the CPU.
 
-The shards' rf_ctx is replaced by a numpy stand-in with the two-phase step protocol
-(env_step_begin / env_step_end); what is under test is what the sharded environment adds:
+The shards' rf_ctx is replaced by a numpy stand-in with the two-phase step protocols
+(env_step_plan / env_step_run; env_step_begin / env_step_end_given in the exact mode); what is under test is what the sharded environment adds:
 contiguous env ranges, global RNG-state offsets, one thread per shard, the initializer's rows
 handed out in GLOBAL index order across shards, host concatenation.  The real thing runs in
 tests/test_gpu_environment.py::test_sharded_environment_equals_one_device."""
@@ -66,6 +66,14 @@ class FakeContext:
         self.state[truncated] = rows
         self.steps[truncated] = 0
         return self._obs()
+
+    def env_step_plan(self, actions):  # the default mode's halves: the cut is BEFORE the render
+        return self.env_step_begin(actions)[2]
+
+    def env_step_run(self, rows):
+        truncated = self.pending.copy()
+        rewards = self.state.sum(axis=1).astype(np.float64)  # (before the rows are applied, as env_step_begin reports them)
+        return self.env_step_end(rows), rewards, truncated
 
     def env_render_states(self, states):
         """Exact mode: "focus values" that say where a row was rendered (slot = first env + local row)."""
