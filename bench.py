@@ -239,11 +239,16 @@ class Ranks:
 # figures taken from the committed rocprofv3 PMC summary (profiles/<tag>_pmc.json)
 # ---------------------------------------------------------------------------------------------
 def kernel_key(name):
-    """'void rf::render_kernel_coop2<true, 1, 4, 32>(rf::RenderArgs)' -> 'render_kernel_coop2<true,1,4,32>'."""
+    """'void rf::render_kernel_coop2<true, 1, 4, 32, false>(rf::RenderArgs)' -> 'render_kernel_coop2<true,1,4,32>'
+    (the profiler prints the defaulted last template argument -- false: single pass --, the library's own name for
+    the instance leaves it out; the two-pass instance of the fused env step keeps its ',true')."""
     name = name.split("(")[0].strip()
     if name.startswith("void "):
         name = name[5:]
-    return name.replace("rf::", "").replace(" ", "")
+    name = name.replace("rf::", "").replace(" ", "")
+    if name.startswith("render_kernel_coop2<") and name.endswith(",false>"):
+        name = name[:-len(",false>")] + ">"
+    return name
 
 
 def committed_profile(kernel, frame, spp):
@@ -632,6 +637,7 @@ def main(argv=None):
         ctx = contexts[0]
         env.reset()
         pixels_before_first_step = _native.pixels_rendered()
+        kernel_before_first_step = ctx.render_kernel_name()
     else:
         placements = [rank_placement(ranks.rank, ranks.local_rank)]
     if not args.sharded_env:
@@ -731,9 +737,13 @@ def main(argv=None):
             per_step = n_local * frame * frame * 3 * (1.0 + total_resets / max(args.steps, 1) / max(total_envs, 1))
             out["pcie_bytes_per_step_per_gpu"] = {"device_to_host": per_step, "host_to_device": per_step}
         if env is not None:
-            # every render launch of this process used the same kernel instance when the 13-environment
-            # extrema render (cached_focus_extrema: same frame size and sample count) is among them
-            out["render_pixels_by_kernel"] = {kernel_key(ctx.render_kernel_name()): _native.pixels_rendered()}
+            # the renders before the first step (reset, the 13-environment extrema render of cached_focus_extrema:
+            # same frame size and sample count) use the single-pass instance of the kernel, the fused steps the
+            # two-pass one (separate launches: the same instance throughout)
+            by_kernel = {kernel_key(kernel_before_first_step): pixels_before_first_step}
+            stepped = kernel_key(ctx.render_kernel_name())
+            by_kernel[stepped] = by_kernel.get(stepped, 0) + _native.pixels_rendered() - pixels_before_first_step
+            out["render_pixels_by_kernel"] = by_kernel
             out["render_pixels_before_first_step"] = pixels_before_first_step
         if timing is not None:
             # full renders + the partial auto-reset renders of rank 0 (of shard 0 with --sharded-env)

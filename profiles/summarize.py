@@ -70,6 +70,8 @@ def main(tag):
             e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
         # pixels a wave of the render kernels owns (render_kernel_coop2: 3 pixel sets per thread)
         key = k.replace("void ", "").replace("rf::", "").replace(" ", "")
+        if key.startswith("render_kernel_coop2<") and key.endswith(",false>"):  # (bench.kernel_key: the library's own name)
+            key = key[:-len(",false>")] + ">"
         if key in pixels_by_kernel and e.get("SQ_WAVES"):
             e["pixels"] = float(pixels_by_kernel[key])
             e["pixels_per_wave"] = e["pixels"] / e["SQ_WAVES"]
@@ -119,14 +121,14 @@ def main(tag):
     # static VALU mix of the profiled render kernel instance by gfx950 issue class (tools/isa_mix.py on the
     # listing `make -C reinfocus_amd/csrc asm` writes), with the per-class costs measured by tools/ubench/pairbench
     kernel = (meta["config"] or {}).get("kernel") or ""
-    match = __import__("re").match(r"render_kernel_coop2<(true|false), (\d+), (\d+), (\d+)(, true)?>", kernel)
+    match = __import__("re").match(r"render_kernel_coop2<(true|false), (\d+), (\d+), (\d+)(, true|, false)?>", kernel)
     listing = os.path.join(root, "..", "reinfocus_amd", "csrc", "rf_abi.gfx950.s")
     if match and os.path.exists(listing):
         sys.path.insert(0, os.path.join(root, "..", "tools"))
         import isa_mix
 
         mangled = "_ZN2rf19render_kernel_coop2ILb%dELi%sELi%sELi%sELb%dEEEvNS_10RenderArgsE" % (
-            1 if match.group(1) == "true" else 0, match.group(2), match.group(3), match.group(4), 1 if match.group(5) else 0)
+            1 if match.group(1) == "true" else 0, match.group(2), match.group(3), match.group(4), 1 if match.group(5) == ", true" else 0)
         counts = isa_mix.mix(isa_mix.kernel_lines(listing, mangled))
         total = float(sum(counts.values()))
         if total:

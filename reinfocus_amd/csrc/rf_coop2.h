@@ -462,6 +462,9 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     for (int j = 0; j < kSets; ++j) {
         const Geometry g0 = geometry(tid);
         g[j] = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull); // dead lanes: any state
+        if (TWO) // (... that is not a loop invariant of the passes: the compiler keeps those in scratch)
+            g[j] = Rng{0x7F4A7C15u ^ (uint32_t)tid, 0x9E3779B9u ^ (uint32_t)tid, 0xD192ED03u ^ (uint32_t)tid,
+                       0xD1B54A32u ^ (uint32_t)tid};
         if (g0.live_of(j)) {
             const ulonglong2 st = a.states[pix_of(g0, j)];
             g[j] = rng_load(st.x, st.y);
