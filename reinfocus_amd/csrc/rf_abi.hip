@@ -27,7 +27,7 @@
 #include "rf_jump.h"
 #include "rf_kernels.h"
 #include "rf_coop2.h"
-#include "rf_general_rect.h"
+#include "rf_general_one.h"
 
 namespace {
 
@@ -88,7 +88,7 @@ struct rf_ctx {
     int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..3 forces one (experiments), -1: pick_tile_layout
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
-    bool general_rect = true; // general renderer: cooperative kernel for one-rectangle worlds (REINFOCUS_GENERAL_RECT=0: literal kernel)
+    bool general_one = true; // general renderer: cooperative kernel for one-rectangle worlds (REINFOCUS_GENERAL_ONE=0: literal kernel)
 
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;
@@ -388,8 +388,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->env_graph_enabled = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
         ctx->tile_layout = (v[0] >= '0' && v[0] <= '5') ? v[0] - '0' : -1;
-    if (const char *v = getenv("REINFOCUS_GENERAL_RECT"))
-        ctx->general_rect = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_GENERAL_ONE"))
+        ctx->general_one = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
@@ -966,14 +966,16 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     const size_t b_cam = (size_t)n * sizeof(rf::GeneralCamera), b_par = (size_t)n * most * width * sizeof(float),
                  b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t);
     // worlds of one rectangle per environment (and frames the quick pixel coordinates are proven for) take the cooperative
-    // kernel of rf_general_rect.h; everything else the literal one
-    bool one_rect = ctx->general_rect && h <= 4096 && w <= 4096;
-    for (int e = 0; one_rect && e < n; ++e)
-        one_rect = sizes[e] == 1 && types[(size_t)e * most] == 1;
+    // kernel of rf_general_one.h; everything else the literal one
+    // worlds of exactly one shape per environment, the same kind in all of them: the cooperative kernel (rf_general_one.h)
+    bool one_shape = ctx->general_one && h <= 4096 && w <= 4096 && width >= 7;
+    const bool one_sphere = one_shape && n > 0 && types[0] == 0;
+    for (int e = 0; one_shape && e < n; ++e)
+        one_shape = sizes[e] == 1 && types[(size_t)e * most] == (one_sphere ? 0 : 1);
     // environments per launch: the grid's y limit, and (cooperative kernel) pixel indices of the fix-up list in 32 bits
     const uint64_t hw64 = (uint64_t)h * (uint64_t)w;
-    const int chunk = one_rect ? (int)std::min<uint64_t>(65535, 0xFFFFFFFFull / hw64) : 65535;
-    const size_t b_redo = one_rect ? 256 + (size_t)std::min<uint64_t>((uint64_t)n, (uint64_t)chunk) * hw64 * sizeof(unsigned) : 0;
+    const int chunk = one_shape ? (int)std::min<uint64_t>(65535, 0xFFFFFFFFull / hw64) : 65535;
+    const size_t b_redo = one_shape ? 256 + (size_t)std::min<uint64_t>((uint64_t)n, (uint64_t)chunk) * hw64 * sizeof(unsigned) : 0;
     const size_t o_par = (b_cam + 255) & ~(size_t)255, o_typ = o_par + ((b_par + 255) & ~(size_t)255),
                  o_siz = o_typ + ((b_typ + 255) & ~(size_t)255), o_redo = o_siz + ((b_siz + 255) & ~(size_t)255),
                  total = o_redo + b_redo;
@@ -1020,8 +1022,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             b.types = a.types + (size_t)e0 * most;
             b.sizes = a.sizes + e0;
             b.n = ne;
-            if (one_rect) {
-                rf::GeneralRectArgs d;
+            if (one_shape) {
+                rf::GeneralOneArgs d;
                 d.g = b;
                 d.redo_count = (unsigned *)(scratch + o_redo);
                 d.redo_list = (unsigned *)(scratch + o_redo + 256);
@@ -1037,14 +1039,22 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                 const dim3 tiles((unsigned)(((w + 127) / 128) * ((h + 2 * rf::kSets - 1) / (2 * rf::kSets))), ne);
                 const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
                 const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
-                if (pow2) {
-                    hipLaunchKernelGGL(rf::render_general_rect_kernel<true>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
+                if (one_sphere && pow2) {
+                    hipLaunchKernelGGL((rf::render_general_one_kernel<true, true>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
                     hipLaunchKernelGGL(rf::render_general_fixup_kernel<true>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_rect_kernel<true>";
-                } else {
-                    hipLaunchKernelGGL(rf::render_general_rect_kernel<false>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
+                    ctx->render_kernel = "render_general_one_kernel<true, true>";
+                } else if (one_sphere) {
+                    hipLaunchKernelGGL((rf::render_general_one_kernel<false, true>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
                     hipLaunchKernelGGL(rf::render_general_fixup_kernel<false>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_rect_kernel<false>";
+                    ctx->render_kernel = "render_general_one_kernel<false, true>";
+                } else if (pow2) {
+                    hipLaunchKernelGGL(rf::render_general_one_kernel<true>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
+                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<true>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
+                    ctx->render_kernel = "render_general_one_kernel<true>";
+                } else {
+                    hipLaunchKernelGGL(rf::render_general_one_kernel<false>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
+                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<false>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
+                    ctx->render_kernel = "render_general_one_kernel<false>";
                 }
             } else if (pow2) {
                 hipLaunchKernelGGL(rf::render_general_kernel<true>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
@@ -1056,7 +1066,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             he = hipGetLastError();
         }
         ctx->general_redo_last = 0;
-        if (he == hipSuccess && one_rect) // (diagnostics: rf_general_redo_pixels)
+        if (he == hipSuccess && one_shape) // (diagnostics: rf_general_redo_pixels)
             he = hipMemcpyAsync(&ctx->general_redo_last, scratch + o_redo, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (he == hipSuccess)

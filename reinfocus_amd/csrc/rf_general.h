@@ -331,7 +331,7 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
 struct GeneralCamera {
     float f[18]; // lower_left, horizontal, vertical, origin, u, v
     double lens_radius;
-    // per-environment constants of general_ray for the cooperative single-rectangle kernel (rf_general_rect.h), which
+    // per-environment constants of general_ray for the cooperative single-rectangle kernel (rf_general_one.h), which
     // reads them into scalar registers instead of keeping 18 vector registers of loop invariants: float64(u),
     // float64(v) (vector.py:190 promotes the float32 components when it scales them by the float64 lens offsets) and
     // the leading `0 + a` of the two three-term sums

@@ -1,27 +1,32 @@
-// rf_general_rect.h -- the general renderer for worlds of ONE rectangle per environment, on the
-// fast path's cooperative organisation:
+// rf_general_one.h -- the general renderer for worlds of ONE shape per environment -- one rectangle
+// in every environment, or one sphere in every environment --, on the fast path's cooperative organisation:
 //
-//   render_general_rect_kernel<POW2>    every pixel: render_kernel_coop2's structure (three pixels per thread, masks in
-//                                       scalar registers, in-wave / block-cooperative rejection tails: rf_coop2.h) with
-//                                       the general renderer's arithmetic -- per-environment camera with float64 lens
-//                                       products, any z-aligned rectangle, any checker frequencies
+//   render_general_one_kernel<POW2, SPHERE>  every pixel: render_kernel_coop2's structure (three pixels per thread, masks
+//                                       in scalar registers, in-wave / block-cooperative rejection tails: rf_coop2.h)
+//                                       with the general renderer's arithmetic -- per-environment camera with float64
+//                                       lens products, any z-aligned rectangle or any sphere, any checker frequencies
 //   render_general_fixup_kernel<POW2>   the literal per-pixel code (rf_general.h) for the pixels the first kernel left
 //
-// Why this class of scenes.  With a single rectangle in the world a scattered ray cannot hit anything: it starts in the
-// rectangle's plane and leaves it (direction (q0, q1, 1 + q2), |q| < 1), so find_colour (physics.py:95-145) is one hit
-// test, one random_in_unit_sphere, one more hit test that misses, and the sky -- the shape of the fast path's sample, and
-// none of the per-set state (origin, direction, hit record) that makes packing unprofitable for general worlds
-// (profiles/r04_ab.txt sections 2 and 5: with bounces a pixel set costs ~30 registers, here 3).  Worlds with spheres or
-// several shapes take the literal kernel.
+// Why this class of scenes.  With a single shape in the world a scattered ray cannot hit anything: off a rectangle it
+// starts in the rectangle's plane and leaves it (direction (q0, q1, 1 + q2), |q| < 1), off a sphere it starts on the
+// surface and points outwards (n + q) -- so find_colour (physics.py:95-145) is one hit test, one random_in_unit_sphere,
+// one more hit test that misses, and the sky: the shape of the fast path's sample, and none of the per-set state
+// (origin, direction, hit record) that makes packing unprofitable for general worlds (profiles/r04_ab.txt sections 2
+// and 5: with bounces a pixel set costs ~30 registers, here 3: what the second test needs -- the plane test's numerator,
+// or the hit point).  Worlds with several shapes, or of different kinds in different environments, take the literal kernel.
 //
-// Exactness.  Two things are decided here in float32 only, and a pixel for which float32 cannot decide is left alone --
+// Exactness.  A few things are decided here in float32 only, and a pixel for which float32 cannot decide is left alone --
 // its RNG state is not stored, its index goes to a list, the fix-up kernel renders it with the literal code from that
 // untouched state (the colour of a hit only scales the attenuation, physics.py:67-92: neither the path nor the number of
 // draws depends on it, so abandoning a pixel at any point is harmless):
-//   * the checker sign of a texture coordinate when frequency x coordinate is within 2^-20 of an integer
-//     (checker_sign_general's own float32 test; the reference's float64 sine decides otherwise);
-//   * the second hit test: the scattered ray's plane parameter t2 = (z - p.z) / (1 + q2) must be below t_min or above
-//     t_max as the reference evaluates it; anything else (a ray that grazes the plane it started in) abstains.
+//   * the checker sign of a rectangle's texture coordinate when frequency x coordinate is within 2^-20 of an integer
+//     (checker_sign_general's own float32 test; the reference's float64 sine decides otherwise), and a sphere's checker
+//     colour when sphere_red's float32 approximation of (u, v) is too close to a checker edge (rf_general.h: the margin
+//     at which the literal code calls the float64 atan2 / acos);
+//   * the second hit test.  Rectangle: the scattered ray's plane parameter t2 = (z - p.z) / (1 + q2) must be below t_min
+//     or above t_max as the reference evaluates it.  Sphere: sphere_hit's discriminant must be negative or its float32
+//     certain-miss test (rf_general.h: a ray pointing away from the centre whose far root lies below t_min) must hold.
+//     Anything else -- a ray that grazes the surface it started on -- abstains.
 // Everything else is the literal arithmetic of rf_general.h, operation by operation (tests/test_gpu_general.py: frames
 // and final RNG states equal the oracle's, no pixel budget).
 #pragma once
@@ -31,7 +36,7 @@
 
 namespace rf {
 
-struct GeneralRectArgs {
+struct GeneralOneArgs {
     GeneralArgs g;
     unsigned *redo_count; // [1], zeroed before the launch
     unsigned *redo_list;  // [n * hw]: pixel indices (e * hw + p within the launch) for the fix-up kernel
@@ -75,11 +80,29 @@ __device__ __forceinline__ int checker_sign_quick(float f, float u, bool &doubt)
     return (RF_TEST_DOUBT && !quick) ? -sign : sign;
 }
 
-#ifndef RF_GENERAL_RECT_OCC
-#define RF_GENERAL_RECT_OCC 6 // waves per SIMD the register allocator is held to
-#endif
-template <bool POW2>
-__global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_rect_kernel(GeneralRectArgs ra)
+// sphere_red's float32 decision (rf_general.h: same expressions, same margins), or abstention
+__device__ __forceinline__ bool sphere_red_quick(const float n[3], float fu, float fv, bool &doubt)
+{
+    float u, v;
+    sphere_uv_approx(n, u, v);
+    const float mu = fu * u, mv = fv * v;
+    int odd_u, odd_v;
+    const float slack = RF_TEST_DOUBT ? 750.0f : 1.0f; // (the test build: about a fifth of the decisions abstain)
+    const bool quick_u = safe_parity(mu, (__builtin_fabsf(fu) + __builtin_fabsf(mu) + 1.0f) * 2e-6f * slack, odd_u);
+    const bool quick_v = safe_parity(mv, (__builtin_fabsf(fv) + __builtin_fabsf(mv) + 1.0f) * 2e-6f * slack, odd_v);
+    const bool quick = quick_u && quick_v;
+    doubt = doubt || !quick;
+    return (odd_u == odd_v) != (RF_TEST_DOUBT && !quick); // (the test build: an abstention's answer is wrong)
+}
+
+constexpr int kGeneralOneOcc = 6; // waves per SIMD the register allocator is held to (5 ... 7 measured: within 1 %)
+// SPHERE: the environment's one shape is a sphere (sphere.py:40-117) instead of a rectangle.  A ray that scattered off
+// it starts on its surface and points outwards (direction n + q, |q| < 1): the second hit test is sphere_hit's own
+// float32 certain-miss test (rf_general.h), and a ray for which that test does not settle it abstains.  Across the sphere
+// call a hit keeps its point p (normal and the second test's oc are (p - centre) again) and two lane masks.
+template <bool POW2, bool SPHERE = false>
+__global__ __launch_bounds__(kBlock2, kGeneralOneOcc) void
+render_general_one_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
     // tile of a block: four waves of 32 x 2 pixels side by side, kSets sets down (128 x 6), as render_kernel_coop2's
@@ -137,16 +160,19 @@ __global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_r
             g[j] = rng_load(st.x, st.y);
         }
     }
-    // the environment's camera and its one rectangle: x_min, x_max, y_min, y_max, z, frequency u, frequency v
+    // the environment's camera and its one shape -- a rectangle's row: x_min, x_max, y_min, y_max, z, frequency u,
+    // frequency v; a sphere's: centre x, y, z, radius, frequency u, frequency v
     const_as<GeneralCamera> &cam = *as_const(a.cameras + e);
     const_as<float> *const rp = as_const(a.params + ((size_t)e * a.most) * a.width);
     const float x_min = rp[0], x_max = rp[1], y_min = rp[2], y_max = rp[3], z_pos = rp[4], freq_u = rp[5], freq_v = rp[6];
+    const float centre[3] = {rp[0], rp[1], rp[2]}, radius = rp[3], sfreq_u = rp[4], sfreq_v = rp[5];
     // block-uniform values computed with vector instructions: keep them in scalar registers (rf_coop2.h)
     auto uniform = [](float v) {
         int bits = __builtin_bit_cast(int, v);
         asm volatile("" : "+v"(bits));
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(bits));
     };
+    const float inv_r = uniform((float)(1.0 / (double)radius)); // float32(1 / radius), as sphere_hit has it
     const float den_u = uniform(x_max - x_min), den_v = uniform(y_max - y_min); // rectangle.py:168-169
     // the two divisors of uv are the rectangle's: with their reciprocals the correctly rounded quotient is three
     // operations (rf_math.h div_by_const, proven for divisors in [2^-40, 2^40]: anything else divides)
@@ -195,12 +221,31 @@ __global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_r
         // in rd[1] and NaN in rd[2] if its colour could not be decided -- its direction is (q0, q1, 1 + q2).
         float rd[kSets][3];
         lanemask hit_m[kSets];
+        lanemask red_m[kSets], doubt_m[kSets]; // (SPHERE: rd holds the hit point)
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
             float p0, p1;
             disc_finish(w[j], p0, p1);
             float o[3], d[3];
             general_ray_scalar(cam, p0, p1, s[j], t[j], o, d);
+            red_m[j] = doubt_m[j] = 0;
+            if (SPHERE) {
+                const float sp[4] = {centre[0], centre[1], centre[2], radius};
+                HitRec rec;
+                rec.p[0] = rec.p[1] = rec.p[2] = 0.0f;
+                rec.n[0] = rec.n[1] = rec.n[2] = 0.0f;
+                bool hit = false, red = false, doubt = false;
+                if (lane_in(live_m[j]))
+                    hit = sphere_hit(sp, o, d, t_min, t_max, rec);
+                hit_m[j] = live_m[j] & lanes_where(hit);
+                if (lane_in(hit_m[j]))
+                    red = sphere_red_quick(rec.n, sfreq_u, sfreq_v, doubt);
+                red_m[j] = hit_m[j] & lanes_where(red);
+                doubt_m[j] = hit_m[j] & lanes_where(doubt);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    rd[j][i] = hit ? rec.p[i] : d[i];
+            } else {
             // rectangle.py:49-99 hit
             const float th = (z_pos - o[2]) / d[2];
             bool hit = !(th < t_min || th > t_max);
@@ -227,6 +272,7 @@ __global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_r
             rd[j][0] = hit ? z_pos - pz : d[0];
             rd[j][1] = hit ? (red ? 1.0f : 0.0f) : d[1];
             rd[j][2] = hit ? (doubt ? __builtin_nanf("") : 0.0f) : d[2];
+            }
             // (one set's ray at a time: interleaved by the scheduler, three sets' float64 temporaries do not fit the budget)
             __builtin_amdgcn_sched_barrier(0);
             w[j][4] = any_u32();
@@ -258,7 +304,34 @@ __global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_r
             float dir[3] = {rd[j][0], rd[j][1], rd[j][2]};
             float ar = 1.0f, ag = 1.0f, ab = 1.0f;
             bool doubt = false;
-            if (lane_in(hit_m[j])) {
+            if (SPHERE && lane_in(hit_m[j])) {
+                float q0, q1, q2;
+                sphere_finish(w[j], q0, q1, q2);
+                // sphere.py:92-101 normal, physics.py:81-87 scatter
+                const float oc[3] = {rd[j][0] - centre[0], rd[j][1] - centre[1], rd[j][2] - centre[2]};
+                dir[0] = add2(oc[0] * inv_r, q0);
+                dir[1] = add2(oc[1] * inv_r, q1);
+                dir[2] = add2(oc[2] * inv_r, q2);
+                ar = lane_in(red_m[j]) ? 1.0f : 0.0f;
+                ag = 1.0f - ar;
+                ab = 0.0f;
+                // the scattered ray against the sphere again (sphere_hit, rf_general.h, up to its certain misses)
+                const float qa = dot3(dir, dir), qb = dot3(oc, dir);
+                const float qc = dot3(oc, oc) - radius * radius;
+                const float disc = qb * qb - qa * qc;
+                bool miss = disc < 0;
+                if (qa > 0.0f && qb > 0.0f) {
+                    const float reach = qb + t_min * qa;
+                    miss = miss || disc < (reach * reach) * 0.99999904632568359375f /* 1 - 2^-20 */;
+                }
+                doubt = !miss || lane_in(doubt_m[j]);
+#if RF_TEST_DOUBT
+                if ((w[j][5] & 0xF000u) == 0) {
+                    doubt = true;
+                    dir[1] = -dir[1];
+                }
+#endif
+            } else if (lane_in(hit_m[j])) {
                 float q0, q1, q2;
                 sphere_finish(w[j], q0, q1, q2);
                 // physics.py:81-87 scatter from the rectangle's normal (0, 0, 1); attenuation red or green
@@ -361,7 +434,7 @@ __global__ __launch_bounds__(kBlock2, RF_GENERAL_RECT_OCC) void render_general_r
 // number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it
 // reads itself.
 template <bool POW2>
-__global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_fixup_kernel(GeneralRectArgs ra)
+__global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_fixup_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
     const unsigned total = *ra.redo_count;

@@ -90,12 +90,12 @@ def test_general_renderer_beyond_one_launch(ctx, oracle):
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
-def test_one_rectangle_worlds_beyond_one_launch(ctx, oracle):
-    """The same for worlds of one rectangle (render_general_rect_kernel + fix-up list per chunk): 65 540 environments of
+def test_one_shape_worlds_beyond_one_launch(ctx, oracle):
+    """The same for worlds of one rectangle (render_general_one_kernel + fix-up list per chunk): 65 540 environments of
     8 x 4 pixels (dword rows: the staged store path) and of 5 x 5 (byte stores), second chunk included."""
     for h, w in ((4, 8), (5, 5)):
         n, spp = 65_540, 2
-        cameras8, (params8, types8, sizes8) = _random_one_rectangle_worlds(np.random.default_rng(9), 8)
+        cameras8, (params8, types8, sizes8) = _random_one_shape_worlds(np.random.default_rng(9), 8)
         reps = -(-n // 8)
         cameras = np.ascontiguousarray(np.tile(cameras8, (reps, 1))[:n])
         params = np.ascontiguousarray(np.tile(params8, (reps, 1, 1))[:n])
@@ -104,7 +104,7 @@ def test_one_rectangle_worlds_beyond_one_launch(ctx, oracle):
         st = oracle.seed_states(n * h * w, 0)
         want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
         got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
-        assert ctx.render_kernel_name().startswith("render_general_rect_kernel")
+        assert ctx.render_kernel_name().startswith("render_general_one_kernel")
         assert np.array_equal(got[:65_535], want[:65_535]), "first chunk"
         assert np.array_equal(got[65_535:], want[65_535:]), "second chunk"
         assert np.array_equal(ctx.get_states(0, n * h * w), st)
@@ -148,9 +148,9 @@ def test_general_equals_fast_path_for_one_rectangle(ctx, oracle):
     assert np.array_equal(ctx.get_states(0, 2 * 64 * 64), st)
 
 
-def _random_one_rectangle_worlds(rng, n):
-    """n environments of one rectangle each (off-centre, any size and checker frequencies) seen by cameras that look from
-    off the axis through apertures of every size: the worlds render_general_rect_kernel takes."""
+def _random_one_shape_worlds(rng, n, kind="rectangle"):
+    """n environments of one rectangle (or one sphere) each (off-centre, any size and checker frequencies) seen by cameras
+    that look from off the axis through apertures of every size: the worlds render_general_one_kernel takes."""
     from reinfocus_amd.graphics import camera, shape, world
 
     cams, envs = [], []
@@ -161,29 +161,54 @@ def _random_one_rectangle_worlds(rng, n):
         z = -rng.uniform(3, 12)
         x, y, sx, sy = rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(0.3, 3.0), rng.uniform(0.3, 3.0)
         tex = (int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+        if kind == "sphere":  # (some of them around the camera: rays that start inside)
+            radius = rng.uniform(0.3, 3.0) if rng.uniform() < 0.9 else rng.uniform(14, 20)
+            envs.append([shape.sphere(shape.v3f(x, y, z), radius, shape.v2f(*tex))])
+            continue
         envs.append([shape.rectangle(shape.v2f(x - sx, x + sx), shape.v2f(y - sy, y + sy), z, shape.v2f(*tex))])
     return camera.Cameras(*cams).device_data(), world.Worlds(*envs).device_data()
 
 
+@pytest.mark.parametrize("kind", ["rectangle", "sphere"])
 @pytest.mark.parametrize("n,h,w,spp,seed", [(5, 40, 56, 6, 1), (3, 96, 64, 8, 2), (7, 33, 35, 3, 3), (4, 128, 128, 9, 4),
                                            (2, 300, 300, 4, 5), (3, 16, 260, 5, 6), (2, 7, 500, 2, 7), (6, 64, 64, 20, 8)])
-def test_one_rectangle_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, oracle, n, h, w, spp, seed):
-    """Worlds of one rectangle per environment go through render_general_rect_kernel (rf_general_rect.h: the fast path's
+def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, oracle, n, h, w, spp, seed, kind):
+    """Worlds of one rectangle per environment go through render_general_one_kernel (rf_general_one.h: the fast path's
     organisation with the general renderer's arithmetic) + the fix-up kernel: frames and final RNG states bit-identical to
     the oracle's general path for power-of-two and other frames, widths that are not multiples of four (byte stores),
     partial tiles, frames wider than high, and switching back to the literal kernel gives the same."""
     rng = np.random.default_rng(seed)
-    cameras, (params, types, sizes) = _random_one_rectangle_worlds(rng, n)
+    cameras, (params, types, sizes) = _random_one_shape_worlds(rng, n, kind)
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
-    assert ctx.render_kernel_name().startswith("render_general_rect_kernel")
+    assert ctx.render_kernel_name().startswith("render_general_one_kernel")
+    assert ctx.render_kernel_name().endswith(", true>") == (kind == "sphere")
     differing = np.any(got != want, axis=-1).sum()
     assert differing == 0, f"{differing} of {n * h * w} pixels differ"
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
-def test_every_abstention_of_the_rectangle_kernel_is_repaired(oracle, tmp_path):
+def test_one_shape_worlds_of_both_kinds_take_the_literal_kernel(ctx, oracle):
+    """The cooperative kernel is compiled for one kind of shape per launch: a batch whose environments hold one
+    rectangle here and one sphere there is rendered by the literal kernel (and equals the oracle as any batch does)."""
+    rng = np.random.default_rng(31)
+    cam_r, (par_r, typ_r, siz_r) = _random_one_shape_worlds(rng, 2, "rectangle")
+    cam_s, (par_s, typ_s, siz_s) = _random_one_shape_worlds(rng, 3, "sphere")
+    cameras = np.ascontiguousarray(np.concatenate([cam_r, cam_s]))
+    params = np.ascontiguousarray(np.concatenate([par_r, np.pad(par_s, ((0, 0), (0, 0), (0, 1)))]))  # (7 / 6 values per row)
+    types = np.ascontiguousarray(np.concatenate([typ_r, typ_s]))
+    sizes = np.ascontiguousarray(np.concatenate([siz_r, siz_s]))
+    n, h, w, spp = 5, 32, 48, 5
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+    got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+    assert ctx.render_kernel_name().startswith("render_general_kernel")
+    assert np.array_equal(got, want) and np.array_equal(ctx.get_states(0, n * h * w), st)
+
+
+@pytest.mark.parametrize("kind", ["rectangle", "sphere"])
+def test_every_abstention_of_the_one_shape_kernel_is_repaired(oracle, tmp_path, kind):
     """The single-rectangle kernel abstains on a pixel whose checker colour float32 cannot decide, or whose scattered ray
     grazes the plane it left, and the fix-up kernel renders those pixels literally.  That happens about once in 10^4
     pixels, and a decision inside the margin is almost always right anyway: an abstention that got lost would go
@@ -198,7 +223,7 @@ def test_every_abstention_of_the_rectangle_kernel_is_repaired(oracle, tmp_path):
     rng = np.random.default_rng(21)
     out = tmp_path / "out.npz"
     for n, h, w, spp in ((4, 64, 64, 6), (3, 40, 52, 5)):
-        cameras, (params, types, sizes) = _random_one_rectangle_worlds(rng, n)
+        cameras, (params, types, sizes) = _random_one_shape_worlds(rng, n, kind)
         np.savez(tmp_path / "scene.npz", cameras=cameras, params=params, types=types, sizes=sizes)
         script = (
             "import sys; sys.path.insert(0, %r)\n"
@@ -214,7 +239,7 @@ def test_every_abstention_of_the_rectangle_kernel_is_repaired(oracle, tmp_path):
         got = np.load(out)
         st = oracle.seed_states(n * h * w, 0)
         want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
-        assert str(got["kernel"]).startswith("render_general_rect_kernel")
+        assert str(got["kernel"]).startswith("render_general_one_kernel")
         assert int(got["redo"]) > n * h * w // 20, "the test build should abstain on many pixels"
         assert np.array_equal(got["frames"], want)
         assert np.array_equal(got["states"], st)
