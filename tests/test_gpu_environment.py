@@ -1,7 +1,11 @@
 """GPU tests of the caller side: FocusObserver and the DiscreteSteps-v0 harness."""
 
+import os
+
 import numpy as np
 import pytest
+
+from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -547,6 +551,52 @@ def test_planned_step_equals_the_whole_step(fused, monkeypatch):
     halves.step(rng.integers(0, 13, n))
     whole.close()
     halves.close()
+
+
+@pytest.mark.parametrize("build,height", [("libreinfocus_skew.so", 128), ("libreinfocus_skew.so", 100),
+                                          ("libreinfocus_cap32.so", 128)])
+def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
+    """The two-pass instance of the render kernel (the fused step's: a block renders its tile, then the tile of the
+    environment that takes its slot in the auto-reset's compacted set) under the test builds that
+    tests/test_gpu_parity.py runs the single-pass instance under -- delayed waves (RF_TEST_SKEW: the passes are
+    ordered against each other by barriers alone) and tiny cooperative lists (overflow paths in both passes) --, in a
+    child process, against the shipped library's run of the same steps (which the tests above pin to the numpy glue)."""
+    import subprocess
+    import sys
+
+    from reinfocus_amd.environments import harness
+
+    so = helpers.built("tests/gpucheck", build)
+    n, steps = 12, 7
+    kw = dict(max_episode_steps=3, num_envs=n, frame_height=height, samples_per_pixel=4, seed=29, device=0)
+    actions = np.random.default_rng(3).integers(0, 13, (steps, n))
+    np.save(tmp_path / "actions.npy", actions)
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reinfocus_amd.environments import harness\n"
+        "env = harness.DeviceVectorDiscreteSteps(**%r)\n"
+        "out = [env.reset()[0]]\n"
+        "for a in np.load(%r):\n"
+        "    o, r, _, t, _ = env.step(a)\n"
+        "    out += [o, r, t]\n"
+        "assert env._ctx.env_last_step_branch() == 'fused-graph' and env._ctx.render_kernel_name().endswith(', true>')\n"
+        "np.savez(%r, *out, states=env._ctx.get_states(0, 3 * %d))\n"
+    ) % (helpers.ROOT, kw, str(tmp_path / "actions.npy"), str(tmp_path / "out.npz"), height * height)
+    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_HIP_LIB=so))
+    got = np.load(tmp_path / "out.npz")
+    env = harness.DeviceVectorDiscreteSteps(**kw)
+    want = [env.reset()[0]]
+    ended = 0
+    for a in actions:
+        o, r, _, t, _ = env.step(a)
+        want += [o, r, t]
+        ended += int(t.sum())
+    assert ended > n
+    for i, w in enumerate(want):
+        assert np.array_equal(got[f"arr_{i}"], w), i
+    assert np.array_equal(got["states"], env._ctx.get_states(0, 3 * height * height))
+    env.close()
 
 
 def test_env_step_graph_capture_failure_falls_back(monkeypatch):
