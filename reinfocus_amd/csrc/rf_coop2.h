@@ -408,8 +408,8 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     const float *const scene_cam = (TWO && pass == 1) ? a.cam_dyn2 : a.cam_dyn;
     const float *const scene_rect = (TWO && pass == 1) ? a.rect2 : a.rect;
     uint8_t *const out_frames = (TWO && pass + 1 < passes) ? a.frames2 : a.frames;
-    if (TWO && pass != 0)
-        __syncthreads(); // (the first pass's last reads of the stage; the counters below)
+    // (second pass: the first one's row stores still read the stage -- words4 -- while the counters are cleared here;
+    // nothing of this pass writes a cooperative array before the barrier below: tests/test_sync_model.py)
     if (tid < 2)
         lds.cnt[tid] = 0;
     if (tid == 2)

@@ -35,7 +35,7 @@ class Wave:
 # accesses of one phase that cannot collide with each other although several waves make them in one epoch: the slots
 # are dealt by an atomic (park, round-1 survivors), indexed by the worker's own thread (rounds), or the owner's own
 # (collect); atomics on one word are ordered by the LDS unit
-SELF_COMPATIBLE = {"park", "round1", "round2", "finish", "collect", "count"}
+SELF_COMPATIBLE = {"park", "round1", "round2", "finish", "collect", "count", "stage", "store"}
 
 
 def overlap(array_a, array_b):
@@ -110,12 +110,17 @@ def cooperative_call(wave, dim, parity, counter, outcome, fenced, sample):
         wave.barrier()  # B4
 
 
-def sample_loop(outcomes, in_wave_disc, fenced, alternate, n_waves=3):
+def sample_loop(outcomes, in_wave_disc, fenced, alternate, n_waves=3, passes=1):
     """The cooperative part of the sample loop for every combination in `outcomes` (one entry per sample: the sphere
-    call's outcome, and for the block-wide disc call the disc call's)."""
+    call's outcome, and for the block-wide disc call the disc call's).  passes = 2: the two-pass instance of the fused
+    environment step (the same samples again after the first pass's frame has gone through the stage)."""
     waves = [Wave(i) for i in range(n_waves)]
     for wave in waves:
-        wave.barrier()  # the kernel's prologue: counters cleared, then __syncthreads
+      for p in range(passes):
+        if wave.index == 0:  # threads 0 .. 2 clear the counters
+            for counter in ("cnt0", "cnt1", "cnt2"):
+                wave.touch("clear", counter, W)
+        wave.barrier()  # the pass's prologue: counters cleared, then __syncthreads
         for k, (disc, sphere) in enumerate(outcomes):
             if in_wave_disc:
                 # disc_tails_wave: the wave's own quarter of state[0], nothing else
@@ -127,6 +132,9 @@ def sample_loop(outcomes, in_wave_disc, fenced, alternate, n_waves=3):
             counter = f"cnt{k & 1}" if (in_wave_disc and alternate) else "cnt1"
             cooperative_call(wave, 3, 1, counter, sphere, in_wave_disc and fenced, k)
         wave.barrier()  # end of the loop: the cooperative arrays become the frame stage
+        wave.touch("stage", "words4", W)  # every thread its own bytes
+        wave.barrier()
+        wave.touch("store", "words4", R)  # rows of the tile, read by other threads than wrote them
     return waves
 
 
@@ -169,3 +177,14 @@ def test_the_checker_finds_what_each_measure_is_there_for(fenced, alternate):
     if not alternate:
         assert (("count", "cnt1"), ("park", "cnt1")) in found  # the empty-list exit: no B4 there by design
     assert found
+
+
+@pytest.mark.parametrize("in_wave_disc", [True, False])
+def test_the_two_passes_of_the_fused_step_need_no_barrier_of_their_own(in_wave_disc):
+    """render_kernel_coop2<.., TWO = true>: a block's second pass re-uses every cooperative array and the stage.  The
+    barrier at the top of every pass (behind the counter clears) is enough: the first pass's row stores (reads of the
+    stage) and the clears share an epoch without touching the same words, and everything else of the second pass comes
+    after it."""
+    for outcomes in all_outcomes(2, with_disc=not in_wave_disc):
+        found = races(sample_loop(outcomes, in_wave_disc, fenced=True, alternate=True, passes=2))
+        assert not found, (outcomes, found[:3])
