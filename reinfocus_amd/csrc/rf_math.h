@@ -369,6 +369,25 @@ RF_HD void disc_sample(Rng &g, float &p0, float &p1)
     disc_finish(w, p0, p1);
 }
 
+// sq_len of the three exact components of a sphere candidate, one component at a time: the block that calls this is
+// taken once in ~10^4 attempts, and with all three conversions in flight it is where the render kernels' register
+// budget spills
+RF_HD float sq_len_exact_sequential(const uint32_t w[6])
+{
+    float aa = exact_pm1(w[0], w[1]);
+    aa = aa * aa;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(aa));
+#endif
+    float bb = exact_pm1(w[2], w[3]);
+    bb = aa + bb * bb; // (not contracted: -ffp-contract=off)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(bb));
+#endif
+    const float cc = exact_pm1(w[4], w[5]);
+    return bb + cc * cc;
+}
+
 // One attempt of physics.py:20-44 random_in_unit_sphere: three draws (raw words kept in
 // w = {ah, al, bh, bl, ch, cl}); true when the reference accepts the candidate, i.e. when
 // float32(q0**2) + float32(q1**2) + float32(q2**2) < 1.
@@ -381,7 +400,7 @@ RF_HD bool sphere_attempt(Rng &g, uint32_t w[6])
     const float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
     bool accept = sq < 1.0f - kAcceptBand;
     if (__builtin_expect(!accept && sq < 1.0f + kAcceptBand, 0))
-        accept = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5])) < 1.0f;
+        accept = sq_len_exact_sequential(w) < 1.0f;
     return accept;
 }
 
@@ -393,7 +412,7 @@ RF_HD float sphere_attempt_sq(Rng &g, uint32_t w[6]) // see disc_attempt_sq
     const float ta = approx_pm1(w[0]), tb = approx_pm1(w[2]), tc = approx_pm1(w[4]);
     float sq = __builtin_fmaf(ta, ta, __builtin_fmaf(tb, tb, tc * tc));
     if (__builtin_expect(__builtin_fabsf(sq - 1.0f) < kAcceptBand, 0))
-        sq = sq_len(exact_pm1(w[0], w[1]), exact_pm1(w[2], w[3]), exact_pm1(w[4], w[5]));
+        sq = sq_len_exact_sequential(w);
     return sq;
 }
 
