@@ -72,6 +72,7 @@ struct rf_ctx {
     ulonglong2 *d_states = nullptr;
     uint64_t n_states = 0;
     ulonglong2 *d_mats = nullptr;
+    int *d_zero = nullptr; // a device int that stays 0: the second-pass count of a two-pass kernel launched for one pass
     // rf_render_general re-creates seed-0 states for every call, as the reference does (render.py:115): a copy of
     // the freshly seeded array turns all but the first seeding of a size into a device-to-device copy
     ulonglong2 *d_seed_cache = nullptr;
@@ -85,6 +86,7 @@ struct rf_ctx {
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
     bool two_sets = true; // several pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
+    bool strip = true; // a frame's last w % 64 <= 48 columns as tiles of 48 x 16 (REINFOCUS_RENDER_STRIP=0: one tile shape)
     int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..3 forces one (experiments), -1: pick_tile_layout
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
@@ -380,6 +382,8 @@ int rf_create(int device, rf_ctx **out)
     ctx->tab = make_checker_table();
     if (const char *v = getenv("REINFOCUS_RENDER_COOP"))
         ctx->coop = v[0] != '0';
+    if (const char *v = getenv("REINFOCUS_RENDER_STRIP"))
+        ctx->strip = strcmp(v, "0") != 0;
     if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
         ctx->two_sets = v[0] != '1';
     if (const char *v = getenv("REINFOCUS_ENV_FUSED"))
@@ -413,6 +417,10 @@ int rf_create(int device, rf_ctx **out)
     if (he == hipSuccess)
         he = hipMemcpy(ctx->d_mats, tables.data(), sizeof(rf::Mat128) * rf::kSeedMats,
                        hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+        he = hipMalloc((void **)&ctx->d_zero, 256);
+    if (he == hipSuccess)
+        he = hipMemset(ctx->d_zero, 0, 256);
     if (he != hipSuccess) {
         set_err("rf_create: %s", hipGetErrorString(he));
         rf_destroy(ctx);
@@ -439,6 +447,7 @@ int rf_destroy(rf_ctx *ctx)
     }
     if (ctx->d_states) (void)hipFree(ctx->d_states);
     if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->d_seed_cache) (void)hipFree(ctx->d_seed_cache);
     if (ctx->d_cam) (void)hipFree(ctx->d_cam);
     if (ctx->d_rect) (void)hipFree(ctx->d_rect);
@@ -611,6 +620,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     a.rect2 = second ? second->rect : nullptr;
     a.frames2 = second ? ctx->d_frames2 : nullptr;
     a.env0 = 0;
+    a.main_tiles = 0;
+    a.strip_x0 = 0;
 
     const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
     {
@@ -642,7 +653,36 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             const dim3 tiles2(((w + layout_w - 1) / layout_w) * ((h + layout_h - 1) / layout_h), ne);
             const dim3 block2(rf::kBlock2);
             const bool lens32 = a.cs.lens_f32 != 0;
-            if (axis && ctx->coop && ctx->two_sets) {
+            // widths beyond 128 that are not a multiple of 64: the remainder (<= 48 columns) as a strip of 48 x 16 tiles
+            // next to the main ones (render_kernel_coop2_strip) instead of a last tile column that is mostly dead lanes
+            // (measured: +4.0 % at 300 px, +2.1 ... 2.4 % at 200 / 400 / 600 px; at 100 px the 16 x 4 pixel waves of
+            // layout 4 are 12 % faster than a 64-column main part: profiles/r04_ab.txt section 17)
+            const int rem = w % 64;
+            if (axis && ctx->coop && ctx->two_sets && ctx->strip && ctx->tile_layout < 0 && !pow2 && w > 128 && rem > 0 &&
+                rem <= 48) {
+                b.strip_x0 = w - rem;
+                const bool wide = b.strip_x0 % 128 == 0; // main tiles of 128 x 6 where they fit, else 64 x 12 (+0.8 % at 300 px)
+                b.main_tiles = wide ? (b.strip_x0 / 128) * ((h + 2 * rf::kSets - 1) / (2 * rf::kSets))
+                                    : (b.strip_x0 / 64) * ((h + 4 * rf::kSets - 1) / (4 * rf::kSets));
+                const dim3 tiles_s((unsigned)(b.main_tiles + (h + 15) / 16), ne);
+                // (one instance for one and for two passes -- the two-pass form, which reads its arguments afresh in each
+                // tile shape's code, is also the one that compiles without spills: a single pass is a count of zero)
+                if (!second)
+                    b.count2 = ctx->d_zero;
+                if (lens32 && wide) {
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<1, 4>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<1, 4>";
+                } else if (lens32) {
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<1>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<1>";
+                } else if (wide) {
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0, 4>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<0, 4>";
+                } else {
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<0>";
+                }
+            } else if (axis && ctx->coop && ctx->two_sets) {
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
     if (second) {                                                                                          \
         hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW, true>), tiles2, block2, 0, ctx->stream, b); \

@@ -371,8 +371,13 @@ __device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&
 // arguments, tile and thread geometry: all loop invariants) lives in registers through the sample loop, which has none
 // to spare (34 scalar and 19 vector registers spilled that way).  So every pass reads the arguments afresh through a
 // kernel-argument pointer and takes block and thread indices through registers the compiler cannot see through.
-template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW, bool TWO = false>
-__global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderArgs a_in)
+//
+// ACROSS / REGION: the strip of a frame whose width is not a multiple of the tile's (render_kernel_coop2_strip below).
+// ACROSS puts a thread's kSets pixels side by side (tTileW apart) instead of below each other; REGION says which columns
+// of the frame the launch's tiles of this shape cover: 0 all, 1 [0, strip_x0), 2 [strip_x0, w) (blocks from main_tiles on).
+template <bool POW2, int LENS, int WX, int WW, bool ACROSS, int REGION, bool TWO>
+__device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLds2 &lds,
+                                                  float (&lds_colour)[kColourLds][3][kBlock2])
 {
     // tile of a block: WX waves (of WW x 64 / WW pixels) side by side, 4 / WX down, kSets sets
     constexpr int tWaveW = WW, tWaveH = 64 / WW;
@@ -381,14 +386,13 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     // tails inside the wave and take list slots per wave; the others (float64 pixel coordinates: more registers,
     // more issue-bound) keep the block-wide disc call and per-straggler slots
     constexpr bool kDiscInWave = POW2, kWaveSlots = POW2;
-    constexpr int tWavesX = WX, tTileW = WX * tWaveW, tTileH = (4 / WX) * tWaveH, tTileH2 = tTileH * kSets;
-    __shared__ CoopLds2 lds;
+    constexpr int tWavesX = WX, tTileW = WX * tWaveW, tTileH = (4 / WX) * tWaveH;
+    // set j lies j * (tDx, tDy) from set 0; the block's whole tile is tAllW x tAllH pixels
+    constexpr int tDx = ACROSS ? tTileW : 0, tDy = ACROSS ? 0 : tTileH;
+    constexpr int tAllW = ACROSS ? tTileW * kSets : tTileW, tAllH = ACROSS ? tTileH : tTileH * kSets;
     // the frame staging buffer (kSets * 768 B) reuses the words4 array once the sample loop is over
     static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock2 * 3, "stage does not fit");
     uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.words4);
-    // colour accumulators of the first kColourLds pixel sets live in LDS (one read-modify-write
-    // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
-    __shared__ float lds_colour[kColourLds][3][kBlock2];
 
     if (!TWO && skip_env(a_in.rect, blockIdx.y)) // block-uniform, before any barrier
         return;
@@ -415,9 +419,11 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     if (tid == 2)
         lds.cnt2 = 0;
     __syncthreads();
-    const int tiles_x = (a.w + tTileW - 1) / tTileW;
-    const int tile_y = block_x / tiles_x, tile_x = block_x - tile_y * tiles_x;
-    const bool mirror = (2 * tile_x + 1) * tTileW > a.w; // see render_kernel_coop
+    const int x_origin = REGION == 2 ? a.strip_x0 : 0, x_end = REGION == 1 ? a.strip_x0 : a.w;
+    const int tile_index = block_x - (REGION == 2 ? a.main_tiles : 0);
+    const int tiles_x = (x_end - x_origin + tAllW - 1) / tAllW;
+    const int tile_y = tile_index / tiles_x, tile_x = tile_index - tile_y * tiles_x;
+    const bool mirror = REGION == 0 && (2 * tile_x + 1) * tTileW > a.w; // see render_kernel_coop
 
     // Pixel geometry of a thread.  Set j covers the rows tTileH * j further down.  All of it is
     // cheap to derive from the thread index, and the sample loop derives it afresh every
@@ -427,14 +433,18 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     struct Geometry {
         int col, row0, x, y0;
         bool live_x;
-        int h;
+        int h, w;
         static __device__ __forceinline__ int opaque(int v)
         {
             asm volatile("" : "+v"(v));
             return v;
         }
-        __device__ __forceinline__ int y_of(int j) const { return y0 + j * tTileH; }
-        __device__ __forceinline__ bool live_of(int j) const { return live_x && y_of(j) < h; }
+        __device__ __forceinline__ int x_of(int j) const { return x + j * tDx; }
+        __device__ __forceinline__ int y_of(int j) const { return y0 + j * tDy; }
+        __device__ __forceinline__ bool live_of(int j) const
+        {
+            return ACROSS ? (x_of(j) < w && y0 < h) : (live_x && y_of(j) < h);
+        }
     };
     static_assert((tWavesX & (tWavesX - 1)) == 0 && (tWaveW & (tWaveW - 1)) == 0, "masks and shifts below");
     const unsigned mirror_mask = mirror ? (unsigned)(tWavesX - 1) : 0u;
@@ -448,14 +458,15 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
         Geometry r;
         r.col = wx * tWaveW + (int)(lane & (unsigned)(tWaveW - 1));
         r.row0 = (int)(wv / (unsigned)tWavesX) * tWaveH + (int)(lane / (unsigned)tWaveW);
-        r.x = tile_x * tTileW + r.col;
-        r.y0 = tile_y * tTileH2 + r.row0;
+        r.x = x_origin + tile_x * tAllW + r.col;
+        r.y0 = tile_y * tAllH + r.row0;
         r.live_x = r.x < a.w;
         r.h = a.h;
+        r.w = a.w;
         return r;
     };
     auto pix_of = [&](const Geometry &q, int j) {
-        return (size_t)e * a.hw + (q.live_of(j) ? (size_t)q.y_of(j) * a.w + q.x : 0);
+        return (size_t)e * a.hw + (q.live_of(j) ? (size_t)q.y_of(j) * a.w + q.x_of(j) : 0);
     };
     Rng g[kSets];
 #pragma unroll
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
     lanemask live_m[kSets]; // lanes whose pixel of set j is inside the frame
 #pragma unroll
     for (int j = 0; j < kSets; ++j)
-        live_m[j] = lanes_where(geometry(tid).x < a.w) & lanes_where(geometry(tid).y_of(j) < a.h);
+        live_m[j] = lanes_where(geometry(tid).x_of(j) < a.w) & lanes_where(geometry(tid).y_of(j) < a.h);
     // per-environment conditions as scalars (a uniform `bool` is a lane mask that vector instructions test)
     const int tmiss_s = __builtin_amdgcn_readfirstlane((int)env0.tmiss);
     for (int k = 0; k < a.spp; ++k) {
@@ -516,8 +527,9 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
             // ((float)y of the further sets by an exact float addition: conversions issue on the slow path)
-            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y0 + (float)(j * tTileH), a.h64, a.w64,
-                                a.inv_w, a.inv_h, a.rw64, a.rh64, s[j], t[j]);
+            sample_coords<POW2>(g[j], gk.x_of(j), gk.y_of(j), ACROSS ? (float)gk.x + (float)(j * tDx) : (float)gk.x,
+                                ACROSS ? (float)gk.y0 : (float)gk.y0 + (float)(j * tDy), a.h64, a.w64, a.inv_w, a.inv_h,
+                                a.rw64, a.rh64, s[j], t[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 w[j][i] = any_u32();
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
         const uint8_t g8 = (uint8_t)(cg[j] * a.scale);
         const uint8_t b8 = (uint8_t)(cb[j] * a.scale);
         if ((a.w & 3) == 0) {
-            const int slot = (j * tTileH + ge.row0) * tTileW + ge.col;
+            const int slot = (j * tDy + ge.row0) * tAllW + j * tDx + ge.col;
             sb[slot * 3 + 0] = r8;
             sb[slot * 3 + 1] = g8;
             sb[slot * 3 + 2] = b8;
@@ -624,21 +636,51 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
         }
     }
     if ((a.w & 3) == 0) {
-        // the tile's rows (tTileW * 3 B each) -> LDS -> coalesced dword stores per row
+        // the tile's rows (tAllW * 3 B each) -> LDS -> coalesced dword stores per row
         __syncthreads();
-        constexpr int kRowDw = tTileW * 3 / 4;
-        for (int i = tid; i < tTileH2 * kRowDw; i += kBlock2) {
+        constexpr int kRowDw = tAllW * 3 / 4;
+        const int x_tile = x_origin + tile_x * tAllW; // (a multiple of 4, like w: every row segment starts on a dword)
+        for (int i = tid; i < tAllH * kRowDw; i += kBlock2) {
             const int r = i / kRowDw, d = i - r * kRowDw;
-            const int yy = tile_y * tTileH2 + r;
-            const int valid_dw = min(tTileW, a.w - tile_x * tTileW) * 3 / 4; // w % 4 == 0
+            const int yy = tile_y * tAllH + r;
+            const int valid_dw = min(tAllW, a.w - x_tile) * 3 / 4; // w % 4 == 0
             if (yy < a.h && d < valid_dw) {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(
-                    out_frames + (((size_t)e * a.h + yy) * a.w + (size_t)tile_x * tTileW) * 3);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(out_frames + (((size_t)e * a.h + yy) * a.w + (size_t)x_tile) * 3);
                 dst[d] = stage[r * kRowDw + d];
             }
         }
     }
   } // pass
+}
+
+template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW, bool TWO = false>
+__global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderArgs a_in)
+{
+    __shared__ CoopLds2 lds;
+    // colour accumulators of the first kColourLds pixel sets live in LDS (one read-modify-write
+    // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
+    __shared__ float lds_colour[kColourLds][3][kBlock2];
+    render_tile_coop2<POW2, LENS, WX, WW, false, 0, TWO>(a_in, lds, lds_colour);
+}
+
+// Frames whose width is not a multiple of 64 (the reference's default 300 x 300 among them).  With tiles of one shape the
+// last tile column covers the remainder plus dead lanes that cost what live ones cost -- 20 of 320 columns at 300 px --;
+// this kernel renders columns [0, strip_x0 = w - w % 64) with the tiles of render_kernel_coop2<false, LENS, MAIN_WX, 32>
+// (128 x 6 where strip_x0 is a multiple of 128, else 64 x 12) and the remaining w % 64 <= 48 columns with tiles of 48 x 16: four waves of 16 x 4 pixels below each other, a
+// thread's three pixels 16 columns apart (44 of 48 columns live at 300 px, 304 of 300 rows: 1.6 % of the lanes dead
+// instead of 6.7 %).  One launch: blocks [0, main_tiles) of a row of the grid are main tiles, the rest strip tiles.
+// (Always the two-pass form of the tile code: a single pass is *count2 == 0.)
+template <int LENS, int MAIN_WX = 2>
+__global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2_strip(RenderArgs a_in)
+{
+    __shared__ CoopLds2 lds;
+    __shared__ float lds_colour[kColourLds][3][kBlock2];
+    if (skip_env(a_in.rect, blockIdx.y)) // (slots a launch for all n environments has to leave alone: never a real rectangle)
+        return;
+    if ((int)blockIdx.x < a_in.main_tiles) // block-uniform
+        render_tile_coop2<false, LENS, MAIN_WX, 32, false, 1, true>(a_in, lds, lds_colour);
+    else
+        render_tile_coop2<false, LENS, 1, 16, true, 2, true>(a_in, lds, lds_colour);
 }
 
 } // namespace rf

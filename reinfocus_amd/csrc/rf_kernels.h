@@ -64,6 +64,8 @@ struct RenderArgs {
     const float *cam_dyn2, *rect2;
     uint8_t *frames2;
     int env0; // index of the launch's first environment (launches hold at most 65535)
+    // render_kernel_coop2_strip: blocks [0, main_tiles) of a grid row render columns [0, strip_x0), the others the rest
+    int main_tiles, strip_x0;
 };
 
 // AXIS / POW2: exact specialisations, see rf_math.h render_pixel.

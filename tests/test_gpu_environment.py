@@ -580,7 +580,7 @@ def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
         "for a in np.load(%r):\n"
         "    o, r, _, t, _ = env.step(a)\n"
         "    out += [o, r, t]\n"
-        "assert env._ctx.env_last_step_branch() == 'fused-graph' and env._ctx.render_kernel_name().endswith(', true>')\n"
+        "assert env._ctx.env_last_step_branch() == 'fused-graph' and (env._ctx.render_kernel_name().endswith(', true>') or 'strip' in env._ctx.render_kernel_name())\n"
         "np.savez(%r, *out, states=env._ctx.get_states(0, 3 * %d))\n"
     ) % (helpers.ROOT, kw, str(tmp_path / "actions.npy"), str(tmp_path / "out.npz"), height * height)
     subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_HIP_LIB=so))

@@ -117,6 +117,26 @@ def test_render_matches_oracle(ctx, oracle, n, h, w, spp):
     assert np.array_equal(got2, want2)
 
 
+@pytest.mark.parametrize("n,h,w,spp", [(3, 37, 132, 3), (2, 100, 164, 4), (2, 300, 300, 2), (3, 70, 176, 3), (2, 45, 165, 3),
+                                       (3, 33, 148, 5), (1, 16, 600, 2), (2, 24, 232, 3), (2, 21, 179, 2), (2, 20, 100, 2)])
+def test_strip_tiles_match_oracle(oracle, tmp_path, n, h, w, spp):
+    """Frames wider than 128 whose width leaves 1 .. 48 columns beyond a multiple of 64 are rendered by
+    render_kernel_coop2_strip: 128 x 6 or 64 x 12 tiles on the left, 48 x 16 tiles (three pixels per thread side by side)
+    for the remainder, in one launch -- remainders of 4, 20, 24 and 40 (main part not a multiple of 128), 36, 37 (odd
+    width: byte stores), 44, 48; 51 columns (> 48) and 100-pixel frames keep one tile shape; heights that fill neither
+    tile shape's rows.  Frames and RNG states equal the oracle's, and the same frames come out of one tile shape."""
+    rng = np.random.default_rng(n * 1000 + w)
+    d = helpers.pack_scene(*helpers.random_scene(rng, n))
+    states = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(d[0], d[1], h, w, spp, states, n_threads=8)  # (advances `states` in place)
+    for overrides in ({}, {"REINFOCUS_RENDER_STRIP": "0"}):
+        frames, final, kernel = _render_in_child(tmp_path, d, n, h, spp, overrides, w=w, want_kernel=True)
+        assert ("strip" in kernel) == (not overrides and w > 128 and w % 64 <= 48), kernel
+        assert ("4>" in kernel) == ("strip" in kernel and (w - w % 64) % 128 == 0), kernel
+        assert np.array_equal(frames, want), (overrides, kernel)
+        assert np.array_equal(final, states), (overrides, kernel)
+
+
 @pytest.mark.parametrize("h,w", [(32, 32), (24, 40)])
 def test_render_general_camera_matches_oracle(ctx, oracle, h, w):
     """A camera frame that is not the canonical one takes the general kernel."""
@@ -367,9 +387,11 @@ def test_rejection_candidate_from_subnormal_bits_is_exact(native):
     assert bad.value == 0, f"{bad.value} of 2^32 candidates differ"
 
 
-def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
+def _render_in_child(tmp_path, scene, n, h, spp, env_overrides, w=None, want_kernel=False):
     """Renders `scene` in a child process whose environment selects another kernel / build of
-    the library (the selection is read once, at rf_create); returns frames and final states."""
+    the library (the selection is read once, at rf_create); returns frames and final states
+    (and the name of the kernel that rendered them)."""
+    w = h if w is None else w
     import subprocess
     import sys
 
@@ -384,10 +406,12 @@ def _render_in_child(tmp_path, scene, n, h, spp, env_overrides):
         "c = _native.Context(0); c.seed(%d, 0, 0)\n"
         "c.set_scene(d['dyn'], d['rect'], d['origin'], d['u'], d['v'], float(d['lens']))\n"
         "f = c.render(%d, %d, %d, %d, to_host=True); s = c.get_states()\n"
-        "np.savez(%r, frames=f, states=s); c.close()\n"
-    ) % (os.path.dirname(here), str(tmp_path / "scene.npz"), n * h * h, n, h, h, spp, str(out))
+        "np.savez(%r, frames=f, states=s, kernel=c.render_kernel_name()); c.close()\n"
+    ) % (os.path.dirname(here), str(tmp_path / "scene.npz"), n * h * w, n, h, w, spp, str(out))
     subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, **env_overrides))
     got = np.load(out)
+    if want_kernel:
+        return got["frames"], got["states"], str(got["kernel"])
     return got["frames"], got["states"]
 
 
