@@ -673,14 +673,14 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
                     hipLaunchKernelGGL((rf::render_kernel_coop2_strip<1, 4>), tiles_s, block2, 0, ctx->stream, b);
                     ctx->render_kernel = "render_kernel_coop2_strip<1, 4>";
                 } else if (lens32) {
-                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<1>), tiles_s, block2, 0, ctx->stream, b);
-                    ctx->render_kernel = "render_kernel_coop2_strip<1>";
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<1, 2>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<1, 2>";
                 } else if (wide) {
                     hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0, 4>), tiles_s, block2, 0, ctx->stream, b);
                     ctx->render_kernel = "render_kernel_coop2_strip<0, 4>";
                 } else {
-                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0>), tiles_s, block2, 0, ctx->stream, b);
-                    ctx->render_kernel = "render_kernel_coop2_strip<0>";
+                    hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0, 2>), tiles_s, block2, 0, ctx->stream, b);
+                    ctx->render_kernel = "render_kernel_coop2_strip<0, 2>";
                 }
             } else if (axis && ctx->coop && ctx->two_sets) {
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
