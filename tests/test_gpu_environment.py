@@ -115,12 +115,13 @@ FIRST_STEP_BRANCH = {"fused-graph": "fused", "graph": "one-sync"}  # (a graph is
 
 
 @pytest.mark.parametrize("branch", list(STEP_BRANCHES))
-@pytest.mark.parametrize("n,height,spp,steps", [(64, 32, 4, 45), (300, 16, 2, 30)])
+@pytest.mark.parametrize("n,height,spp,steps", [(64, 32, 4, 45), (300, 16, 2, 30), (24, 132, 1, 40)])
 def test_device_resident_step_equals_host_harness(n, height, spp, steps, branch, monkeypatch):
     """rf_env_* (transformer, enders, scene packing, normaliser, rewards, auto-reset on the
     GPU) against the numpy harness: identical observations, rewards, flags and states for
     the same seeds and actions, step by step, including the partial auto-reset renders -- on
-    every branch of rf_env_step."""
+    every branch of rf_env_step (132-pixel frames: the strip kernel, with two passes, with a
+    zero count, and with slots marked to be skipped)."""
     from reinfocus_amd.environments import harness
 
     kw = dict(num_envs=n, frame_height=height, samples_per_pixel=spp, seed=11, device=0)
