@@ -1076,26 +1076,27 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                 he = hipMemsetAsync(d.redo_count, 0, sizeof(unsigned), ctx->stream);
                 if (he != hipSuccess)
                     break;
-                const dim3 tiles((unsigned)(((w + 127) / 128) * ((h + 2 * rf::kSets - 1) / (2 * rf::kSets))), ne);
+                // tiles of 128 x 6 or of 64 x 12, whichever leaves fewer dead columns
+                const bool narrow = ((w + 63) / 64) * 64 < ((w + 127) / 128) * 128;
+                const dim3 tiles(narrow ? (unsigned)(((w + 63) / 64) * ((h + 4 * rf::kSets - 1) / (4 * rf::kSets)))
+                                        : (unsigned)(((w + 127) / 128) * ((h + 2 * rf::kSets - 1) / (2 * rf::kSets))), ne);
                 const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
                 const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
-                if (one_sphere && pow2) {
-                    hipLaunchKernelGGL((rf::render_general_one_kernel<true, true>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
-                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<true>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_one_kernel<true, true>";
-                } else if (one_sphere) {
-                    hipLaunchKernelGGL((rf::render_general_one_kernel<false, true>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
-                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<false>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_one_kernel<false, true>";
-                } else if (pow2) {
-                    hipLaunchKernelGGL(rf::render_general_one_kernel<true>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
-                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<true>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_one_kernel<true>";
-                } else {
-                    hipLaunchKernelGGL(rf::render_general_one_kernel<false>, tiles, dim3(rf::kBlock2), 0, ctx->stream, d);
-                    hipLaunchKernelGGL(rf::render_general_fixup_kernel<false>, fix, dim3(rf::kBlock), 0, ctx->stream, d);
-                    ctx->render_kernel = "render_general_one_kernel<false>";
-                }
+#define RF_LAUNCH_ONE(P, S, WXV)                                                                                          \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((rf::render_general_one_kernel<P, S, WXV>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);   \
+        hipLaunchKernelGGL(rf::render_general_fixup_kernel<P>, fix, dim3(rf::kBlock), 0, ctx->stream, d);             \
+        ctx->render_kernel = "render_general_one_kernel<" #P ", " #S ", " #WXV ">";                                    \
+    } while (0)
+                if (one_sphere && pow2 && narrow) RF_LAUNCH_ONE(true, true, 2);
+                else if (one_sphere && pow2) RF_LAUNCH_ONE(true, true, 4);
+                else if (one_sphere && narrow) RF_LAUNCH_ONE(false, true, 2);
+                else if (one_sphere) RF_LAUNCH_ONE(false, true, 4);
+                else if (pow2 && narrow) RF_LAUNCH_ONE(true, false, 2);
+                else if (pow2) RF_LAUNCH_ONE(true, false, 4);
+                else if (narrow) RF_LAUNCH_ONE(false, false, 2);
+                else RF_LAUNCH_ONE(false, false, 4);
+#undef RF_LAUNCH_ONE
             } else if (pow2) {
                 hipLaunchKernelGGL(rf::render_general_kernel<true>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
                 ctx->render_kernel = "render_general_kernel<true>";

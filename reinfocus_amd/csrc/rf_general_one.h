@@ -100,14 +100,18 @@ constexpr int kGeneralOneOcc = 6; // waves per SIMD the register allocator is he
 // it starts on its surface and points outwards (direction n + q, |q| < 1): the second hit test is sphere_hit's own
 // float32 certain-miss test (rf_general.h), and a ray for which that test does not settle it abstains.  Across the sphere
 // call a hit keeps its point p (normal and the second test's oc are (p - centre) again) and two lane masks.
-template <bool POW2, bool SPHERE = false>
+// WX: waves of 32 x 2 pixels side by side in a block's tile -- 4: 128 x 6 pixels (render_kernel_coop2's default layout), 2:
+// 64 x 12, for widths that leave fewer dead columns that way (300 px: 320 instead of 384).
+template <bool POW2, bool SPHERE = false, int WX = 4>
 __global__ __launch_bounds__(kBlock2, kGeneralOneOcc) void
 render_general_one_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
-    // tile of a block: four waves of 32 x 2 pixels side by side, kSets sets down (128 x 6), as render_kernel_coop2's
-    // default layout; the same per-instance choices for the disc tails and the list slots
-    constexpr int tWaveW = 32, tWavesX = 4, tTileW = 128, tTileH = 2, tTileH2 = tTileH * kSets;
+    // tile of a block: WX waves of 32 x 2 pixels side by side, 4 / WX down, kSets sets down; the same per-instance
+    // choices for the disc tails and the list slots as render_kernel_coop2
+    static_assert(WX == 4 || WX == 2, "tile layouts");
+    constexpr int tWaveW = 32, tWaveH = 2, tWavesX = WX, tTileW = WX * tWaveW, tTileH = (4 / WX) * tWaveH,
+                  tTileH2 = tTileH * kSets;
     constexpr bool kDiscInWave = POW2, kWaveSlots = POW2;
     __shared__ CoopLds2 lds;
     static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock2 * 3, "stage does not fit");
@@ -140,7 +144,7 @@ render_general_one_kernel(GeneralOneArgs ra)
         const unsigned ut = (unsigned)t, wv = ut >> 6, lane = ut & 63u;
         Geometry r;
         r.col = (int)(wv & (unsigned)(tWavesX - 1)) * tWaveW + (int)(lane & (unsigned)(tWaveW - 1));
-        r.row0 = (int)(lane / (unsigned)tWaveW);
+        r.row0 = (int)(wv / (unsigned)tWavesX) * tWaveH + (int)(lane / (unsigned)tWaveW);
         r.x = tile_x * tTileW + r.col;
         r.y0 = tile_y * tTileH2 + r.row0;
         r.w = a.w;
