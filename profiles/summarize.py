@@ -123,12 +123,17 @@ def main(tag):
     kernel = (meta["config"] or {}).get("kernel") or ""
     match = __import__("re").match(r"render_kernel_coop2<(true|false), (\d+), (\d+), (\d+)(, true|, false)?>", kernel)
     listing = os.path.join(root, "..", "reinfocus_amd", "csrc", "rf_abi.gfx950.s")
-    if match and os.path.exists(listing):
+    strip = __import__("re").match(r"render_kernel_coop2_strip<(\d+), (\d+)>", kernel)
+    if (match or strip) and os.path.exists(listing):
         sys.path.insert(0, os.path.join(root, "..", "tools"))
         import isa_mix
 
-        mangled = "_ZN2rf19render_kernel_coop2ILb%dELi%sELi%sELi%sELb%dEEEvNS_10RenderArgsE" % (
-            1 if match.group(1) == "true" else 0, match.group(2), match.group(3), match.group(4), 1 if match.group(5) == ", true" else 0)
+        if strip:  # (both tile shapes' code)
+            mangled = "_ZN2rf25render_kernel_coop2_stripILi%sELi%sEEEvNS_10RenderArgsE" % (strip.group(1), strip.group(2))
+        else:
+            mangled = "_ZN2rf19render_kernel_coop2ILb%dELi%sELi%sELi%sELb%dEEEvNS_10RenderArgsE" % (
+                1 if match.group(1) == "true" else 0, match.group(2), match.group(3), match.group(4),
+                1 if match.group(5) == ", true" else 0)
         counts = isa_mix.mix(isa_mix.kernel_lines(listing, mangled))
         total = float(sum(counts.values()))
         if total:
