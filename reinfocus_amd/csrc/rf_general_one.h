@@ -438,7 +438,7 @@ render_general_one_kernel(GeneralOneArgs ra)
 // number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it
 // reads itself.
 template <bool POW2>
-__global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_fixup_kernel(GeneralOneArgs ra)
+__global__ __launch_bounds__(kBlock, kGeneralOcc) void render_general_fixup_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
     const unsigned total = *ra.redo_count;

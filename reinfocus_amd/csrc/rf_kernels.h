@@ -248,14 +248,8 @@ constexpr int kCoopTrips = 2; // in-wave sphere attempts before the cooperative 
 // whole 128-B lines of RNG state as long as kWaveW >= 8).  Measured at the headline config
 // (tools sweep, round 1): 32 x 2 pixel waves side by side (128 x 2 blocks) are 8 % faster
 // than 64 x 1 rows and than squarer tiles.
-#ifndef RF_WAVE_W
-#define RF_WAVE_W 32
-#endif
-#ifndef RF_WAVES_X
-#define RF_WAVES_X 4
-#endif
-constexpr int kWaveW = RF_WAVE_W, kWaveH = 64 / RF_WAVE_W;
-constexpr int kWavesX = RF_WAVES_X, kWavesY = (kBlock / 64) / RF_WAVES_X;
+constexpr int kWaveW = 32, kWaveH = 64 / kWaveW;
+constexpr int kWavesX = 4, kWavesY = (kBlock / 64) / kWavesX;
 constexpr int kTileW = kWavesX * kWaveW, kTileH = kWavesY * kWaveH;
 
 template <bool POW2>
@@ -379,11 +373,9 @@ struct GeneralArgs {
     float scale;
 };
 
-#ifndef RF_GENERAL_OCC
-#define RF_GENERAL_OCC 5
-#endif
+constexpr int kGeneralOcc = 5; // waves per SIMD the literal kernel's register allocation is held to (6: spills, no faster)
 template <bool POW2>
-__global__ __launch_bounds__(kBlock, RF_GENERAL_OCC) void render_general_kernel(GeneralArgs a)
+__global__ __launch_bounds__(kBlock, kGeneralOcc) void render_general_kernel(GeneralArgs a)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4]; // the block's 256 pixels x 3 B, stored as 192 coalesced dwords
     const int e = blockIdx.y;
