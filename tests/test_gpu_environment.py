@@ -10,7 +10,8 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def test_reference_notebook_outputs():
+@pytest.mark.parametrize("pixels_per_thread", ["three", "automatic"])
+def test_reference_notebook_outputs(pixels_per_thread, monkeypatch):
     """examples/environment.ipynb of the reference holds real outputs of the reference
     itself (numba on CUDA + OpenCV 4.9): DiscreteSteps(render_mode="rgb_array"),
     reset() -> [0.46703607, -0.84483975, 0, 0]; render(); step(8) ->
@@ -22,6 +23,8 @@ def test_reference_notebook_outputs():
     the printed digits exactly."""
     from reinfocus_amd.environments import harness
 
+    if pixels_per_thread == "automatic":  # (one environment: the library's own choice is one pixel per thread)
+        monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
     env = harness.DiscreteSteps(render_mode="rgb_array", device=0)
     obs, _ = env.reset(state=[[5.311405, 8.66759]])
     assert obs.dtype == np.float32
@@ -598,6 +601,28 @@ def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
         assert np.array_equal(got[f"arr_{i}"], w), i
     assert np.array_equal(got["states"], env._ctx.get_states(0, 3 * height * height))
     env.close()
+
+
+def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
+    """The library's own choice for launches of few blocks (rf_abi.hip few_blocks: the reference's default single
+    environment among them): one pixel per thread, and with it the schedules of separate launches -- a device-resident
+    environment of 3 x 64 x 64 at 8 samples replays its step as a hipGraph of them, equal to the numpy glue."""
+    from reinfocus_amd.environments import harness
+
+    monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
+    kw = dict(max_episode_steps=4, num_envs=3, frame_height=64, samples_per_pixel=8, seed=5, device=0)
+    host, dev = harness.VectorDiscreteSteps(**kw), harness.DeviceVectorDiscreteSteps(**kw)
+    assert np.array_equal(host.reset()[0], dev.reset()[0])
+    rng = np.random.default_rng(4)
+    for step in range(11):
+        actions = rng.integers(0, 13, 3)
+        for x, y in zip(host.step(actions)[:4], dev.step(actions)[:4]):
+            assert np.array_equal(x, y)
+        assert dev._ctx.env_last_step_branch() == ("one-sync" if step == 0 else "graph")
+        assert dev._ctx.render_kernel_name().startswith("render_kernel_coop<")
+    assert np.array_equal(host._state, dev._state)
+    host.close()
+    dev.close()
 
 
 def test_env_step_graph_capture_failure_falls_back(monkeypatch):

@@ -387,7 +387,7 @@ def test_rejection_candidate_from_subnormal_bits_is_exact(native):
     assert bad.value == 0, f"{bad.value} of 2^32 candidates differ"
 
 
-def _render_in_child(tmp_path, scene, n, h, spp, env_overrides, w=None, want_kernel=False):
+def _render_in_child(tmp_path, scene, n, h, spp, env_overrides, w=None, want_kernel=False, replace_env=False):
     """Renders `scene` in a child process whose environment selects another kernel / build of
     the library (the selection is read once, at rf_create); returns frames and final states
     (and the name of the kernel that rendered them)."""
@@ -408,7 +408,8 @@ def _render_in_child(tmp_path, scene, n, h, spp, env_overrides, w=None, want_ker
         "f = c.render(%d, %d, %d, %d, to_host=True); s = c.get_states()\n"
         "np.savez(%r, frames=f, states=s, kernel=c.render_kernel_name()); c.close()\n"
     ) % (os.path.dirname(here), str(tmp_path / "scene.npz"), n * h * w, n, h, w, spp, str(out))
-    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, **env_overrides))
+    subprocess.check_call([sys.executable, "-c", script],
+                          env=dict(env_overrides) if replace_env else dict(os.environ, **env_overrides))
     got = np.load(out)
     if want_kernel:
         return got["frames"], got["states"], str(got["kernel"])
@@ -459,6 +460,24 @@ def test_delayed_waves_change_nothing(oracle, tmp_path, h):
         frames, final = _render_in_child(tmp_path, d, n, h, spp, dict(overrides, REINFOCUS_HIP_LIB=so))
         assert np.array_equal(frames, want), overrides
         assert np.array_equal(final, states), overrides
+
+
+@pytest.mark.parametrize("n,h,spp,three", [(1, 300, 8, False), (7, 300, 8, True), (9, 256, 9, False), (10, 256, 8, True),
+                                           (2, 128, 7, True), (36, 128, 16, False)])
+def test_few_blocks_take_one_pixel_per_thread(oracle, tmp_path, n, h, spp, three):
+    """Without REINFOCUS_RENDER_SETS the library picks the kernel by the size of the launch: up to 600 000 pixels (about
+    800 blocks of three pixels per thread) at 8 or more samples per pixel -- the reference's own default, one environment
+    of 300 x 300 at 100 samples, is such a launch -- render with one pixel per thread (render_kernel_coop), everything
+    else with three.  Same frames, same RNG states, either way."""
+    rng = np.random.default_rng(n * 100 + h)
+    d = helpers.pack_scene(*helpers.random_scene(rng, n))
+    states = oracle.seed_states(n * h * h, 0)
+    want = oracle.render(d[0], d[1], h, h, spp, states, n_threads=16)  # (advances `states` in place)
+    automatic = {k: v for k, v in os.environ.items() if k != "REINFOCUS_RENDER_SETS"}
+    frames, final, kernel = _render_in_child(tmp_path, d, n, h, spp, automatic, want_kernel=True, replace_env=True)
+    assert kernel.startswith("render_kernel_coop2") == three, kernel
+    assert three or kernel.startswith("render_kernel_coop<"), kernel
+    assert np.array_equal(frames, want) and np.array_equal(final, states)
 
 
 @pytest.mark.parametrize("overrides", [{"REINFOCUS_RENDER_SETS": "1"}, {"REINFOCUS_RENDER_COOP": "0"}],
