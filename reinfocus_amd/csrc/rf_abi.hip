@@ -86,7 +86,8 @@ struct rf_ctx {
     bool axis = false;
     bool coop = true; // block-cooperative sphere loop (REINFOCUS_RENDER_COOP=0 disables)
     bool two_sets = true; // several pixels per thread in the cooperative kernel (REINFOCUS_RENDER_SETS=1 disables)
-    bool auto_sets = true; // ... except for launches of few blocks (few_blocks below; REINFOCUS_RENDER_SETS=3: always three)
+    bool auto_sets = true; // ... except for launches of few blocks, which take the kernel without cooperative tails (few_blocks
+                           // below; REINFOCUS_RENDER_SETS=3 / =1: always three / one pixels per thread with them)
     bool strip = true; // a frame's last w % 64 <= 48 columns as tiles of 48 x 16 (REINFOCUS_RENDER_STRIP=0: one tile shape)
     int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..3 forces one (experiments), -1: pick_tile_layout
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
@@ -585,21 +586,28 @@ struct SecondPass {
 };
 
 // Launches of few blocks -- the reference's own default is ONE environment of 300 x 300 pixels at 100 samples: 119
-// blocks of three pixels per thread on 256 CUs -- are faster with one pixel per thread (render_kernel_coop: three times
-// the blocks, each a third of the work per sample): 1 x 300^2 x 100 687 -> 428 us per step, 4 environments 863 -> 647;
-// three pixels per thread win from about 800 of their blocks on (8 environments of 300^2, 10 of 256^2, 3 of 512^2, 40 of
-// 128^2: profiles/r04_ab.txt section 18).  Below 8 samples per pixel the launches saved by the fused step weigh more.
-bool few_blocks(uint64_t n, uint64_t h, uint64_t w, int spp) { return n * h * w <= 600000 && spp >= 8; }
+// blocks of three pixels per thread on 256 CUs, each running its samples one after the other -- are bound by the
+// latency of a sample, not by issue slots: with one or two waves per SIMD nothing hides the cooperative tails' barriers,
+// and the kernel without them (render_kernel<AXIS, POW2>: one pixel per thread, rejection loops inside the wave) is the
+// fastest form -- 1 x 300^2 x 100: 687 us per step with three pixels per thread, 419 with one and cooperative tails, 289
+// without them; 4 environments 863 / 646 / 563.  Three pixels per thread win from about 650 000 pixels per launch on (10
+// environments of 300^2 or of 256^2, 40 of 128^2: profiles/r04_ab.txt section 18).  Below 8 samples per pixel the
+// launches saved by the fused step weigh more than a sample's latency.
+bool few_blocks(uint64_t n, uint64_t h, uint64_t w, int spp) { return n * h * w <= 650000 && spp >= 8; }
 
-bool three_pixels_per_thread(const rf_ctx *ctx, int n, int h, int w, int spp)
+// which render kernel a launch takes: 3 = three pixels per thread with cooperative tails (render_kernel_coop2 and its
+// strip form), 1 = one pixel per thread with them (render_kernel_coop), 0 = without them (render_kernel)
+int render_form(const rf_ctx *ctx, int n, int h, int w, int spp)
 {
-    return ctx->two_sets && !(ctx->auto_sets && few_blocks((uint64_t)n, (uint64_t)h, (uint64_t)w, spp));
+    if (!ctx->coop || (ctx->auto_sets && few_blocks((uint64_t)n, (uint64_t)h, (uint64_t)w, spp)))
+        return 0;
+    return ctx->two_sets ? 3 : 1;
 }
 
 bool fused_step_possible(const rf_ctx *ctx)
 {
     const rf_env_config &h = ctx->env_host;
-    return ctx->env_fused && ctx->env_axis && ctx->coop && three_pixels_per_thread(ctx, h.n, h.frame_height, h.frame_height, h.spp);
+    return ctx->env_fused && ctx->env_axis && render_form(ctx, h.n, h.frame_height, h.frame_height, h.spp) == 3;
 }
 
 // enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
@@ -611,8 +619,8 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         rc = ensure_frames2(ctx, n, h, w);
     if (rc != RF_OK)
         return rc;
-    const bool sets3 = three_pixels_per_thread(ctx, n, h, w, spp);
-    RF_REQUIRE(!second || (axis && ctx->coop && sets3), "launch_render: no two-pass instance of this kernel");
+    const int form = render_form(ctx, n, h, w, spp);
+    RF_REQUIRE(!second || (axis && form == 3), "launch_render: no two-pass instance of this kernel");
     rf::RenderArgs a;
     a.frames = ctx->d_frames;
     a.states = ctx->d_states;
@@ -676,7 +684,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             // (measured: +4.0 % at 300 px, +2.1 ... 2.4 % at 200 / 400 / 600 px; at 100 px the 16 x 4 pixel waves of
             // layout 4 are 12 % faster than a 64-column main part: profiles/r04_ab.txt section 17)
             const int rem = w % 64;
-            if (axis && ctx->coop && sets3 && ctx->strip && ctx->tile_layout < 0 && !pow2 && w > 128 && rem > 0 &&
+            if (axis && form == 3 && ctx->strip && ctx->tile_layout < 0 && !pow2 && w > 128 && rem > 0 &&
                 rem <= 48) {
                 b.strip_x0 = w - rem;
                 const bool wide = b.strip_x0 % 128 == 0; // main tiles of 128 x 6 where they fit, else 64 x 12 (+0.8 % at 300 px)
@@ -700,7 +708,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
                     hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0, 2>), tiles_s, block2, 0, ctx->stream, b);
                     ctx->render_kernel = "render_kernel_coop2_strip<0, 2>";
                 }
-            } else if (axis && ctx->coop && sets3) {
+            } else if (axis && form == 3) {
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
     if (second) {                                                                                          \
         hipLaunchKernelGGL((rf::render_kernel_coop2<P, L, WX, WW, true>), tiles2, block2, 0, ctx->stream, b); \
@@ -731,10 +739,10 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
 #undef RF_LAUNCH2_ONE
 #undef RF_LAUNCH2
             }
-            else if (axis && ctx->coop && pow2) {
+            else if (axis && form == 1 && pow2) {
                 hipLaunchKernelGGL((rf::render_kernel_coop<true>), tiles, block, 0, ctx->stream, b);
                 ctx->render_kernel = "render_kernel_coop<true>";
-            } else if (axis && ctx->coop) {
+            } else if (axis && form == 1) {
                 hipLaunchKernelGGL((rf::render_kernel_coop<false>), tiles, block, 0, ctx->stream, b);
                 ctx->render_kernel = "render_kernel_coop<false>";
             } else if (axis && pow2) {

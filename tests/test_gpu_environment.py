@@ -605,7 +605,7 @@ def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
 
 def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
     """The library's own choice for launches of few blocks (rf_abi.hip few_blocks: the reference's default single
-    environment among them): one pixel per thread, and with it the schedules of separate launches -- a device-resident
+    environment among them): the kernel without cooperative tails, and with it the schedules of separate launches -- a device-resident
     environment of 3 x 64 x 64 at 8 samples replays its step as a hipGraph of them, equal to the numpy glue."""
     from reinfocus_amd.environments import harness
 
@@ -619,7 +619,7 @@ def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
         for x, y in zip(host.step(actions)[:4], dev.step(actions)[:4]):
             assert np.array_equal(x, y)
         assert dev._ctx.env_last_step_branch() == ("one-sync" if step == 0 else "graph")
-        assert dev._ctx.render_kernel_name().startswith("render_kernel_coop<")
+        assert dev._ctx.render_kernel_name().startswith("render_kernel<")
     assert np.array_equal(host._state, dev._state)
     host.close()
     dev.close()

@@ -7,7 +7,7 @@ run() { local name=$1; shift
 import json,sys; d=json.loads(sys.stdin.read()); print('$name', round(d['value'],1), 'env-steps/s', round(d['ms_per_step']*1000,1), 'us/step', flush=True)"; }
 run e1_300 --envs-per-gpu 1 --frame 300 --spp 100 --steps 300 --warmup 10
 run e6_300 --envs-per-gpu 6 --frame 300 --spp 100 --steps 200 --warmup 10
-run e7_300 --envs-per-gpu 7 --frame 300 --spp 100 --steps 200 --warmup 10
+run e8_300 --envs-per-gpu 8 --frame 300 --spp 100 --steps 200 --warmup 10
 run e1_256 --envs-per-gpu 1 --frame 256 --spp 16 --steps 500 --warmup 10
 run c0 --envs-per-gpu 1 --frame 64 --spp 1 --steps 2000 --warmup 10
 run c1 --envs-per-gpu 256 --frame 128 --spp 4 --steps 1000 --warmup 10
