@@ -92,7 +92,8 @@ struct rf_ctx {
     int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..3 forces one (experiments), -1: pick_tile_layout
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
-    bool general_one = true; // general renderer: cooperative kernel for one-rectangle worlds (REINFOCUS_GENERAL_ONE=0: literal kernel)
+    bool general_one = true; // general renderer: cooperative kernel for one-shape worlds (REINFOCUS_GENERAL_ONE=0: literal kernel)
+    bool general_one_always = false; // ... for launches of every size (REINFOCUS_GENERAL_ONE=1; default: large launches only)
 
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;
@@ -395,7 +396,7 @@ int rf_create(int device, rf_ctx **out)
     if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
         ctx->tile_layout = (v[0] >= '0' && v[0] <= '5') ? v[0] - '0' : -1;
     if (const char *v = getenv("REINFOCUS_GENERAL_ONE"))
-        ctx->general_one = v[0] != '0';
+        ctx->general_one = v[0] != '0', ctx->general_one_always = v[0] == '1';
     if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
         ctx->focus_quad = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
@@ -1036,6 +1037,12 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     // worlds of exactly one shape per environment, the same kind in all of them: the cooperative kernel (rf_general_one.h)
     bool one_shape = ctx->general_one && h <= 4096 && w <= 4096 && width >= 7;
     const bool one_sphere = one_shape && n > 0 && types[0] == 0;
+    // ... for launches that fill the device: the notebooks' one or two environments are a few hundred blocks, bound by the
+    // latency of a sample, and there the literal kernel (one pixel per thread, no barriers) is up to three times faster
+    // (1 x 300^2 x 100: 0.35 ms against 1.02); the cooperative kernel wins from about 2 M pixels per launch on with a
+    // rectangle, 3 M with a sphere (profiles/r04_ab.txt section 19)
+    if (one_shape && !ctx->general_one_always && (uint64_t)n * (uint64_t)h * (uint64_t)w <= (one_sphere ? 3000000u : 2000000u))
+        one_shape = false;
     for (int e = 0; one_shape && e < n; ++e)
         one_shape = sizes[e] == 1 && types[(size_t)e * most] == (one_sphere ? 0 : 1);
     // environments per launch: the grid's y limit, and (cooperative kernel) pixel indices of the fix-up list in 32 bits

@@ -15,6 +15,10 @@ def pytest_configure(config):
     # test asks otherwise (tests/test_gpu_parity.py::test_few_blocks_take_one_pixel_per_thread and the notebook outputs
     # run the automatic choice).
     os.environ.setdefault("REINFOCUS_RENDER_SETS", "3")
+    # likewise the general renderer's kernel for worlds of one shape: the library takes it for launches that fill the
+    # device; the tests render it at every size (test_gpu_general.py::test_small_one_shape_launches_take_the_literal_kernel
+    # runs the library's choice)
+    os.environ.setdefault("REINFOCUS_GENERAL_ONE", "1")
 
 
 def pytest_sessionstart(session):

@@ -191,6 +191,38 @@ def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, 
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
+@pytest.mark.parametrize("kind,n,h,w,spp,cooperative", [("rectangle", 2, 300, 600, 3, False), ("rectangle", 36, 256, 256, 2, True),
+                                                       ("sphere", 36, 256, 256, 2, False), ("sphere", 50, 256, 256, 2, True)])
+def test_small_one_shape_launches_take_the_literal_kernel(oracle, tmp_path, kind, n, h, w, spp, cooperative):
+    """Without REINFOCUS_GENERAL_ONE the library takes the cooperative single-shape kernel only for launches that fill the
+    device (more than 2 M pixels with a rectangle, 3 M with a sphere): the notebooks' one or two environments are bound by
+    the latency of a sample, and the literal kernel is up to three times faster there.  Same frames and states either way."""
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(n + h)
+    cameras, (params, types, sizes) = _random_one_shape_worlds(rng, n, kind)
+    np.savez(tmp_path / "scene.npz", cameras=cameras, params=params, types=types, sizes=sizes)
+    out = tmp_path / "out.npz"
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reinfocus_amd import _native\n"
+        "d = np.load(%r)\n"
+        "c = _native.Context(0)\n"
+        "f = c.render_general(d['cameras'], d['params'], d['types'], d['sizes'], %d, %d, %d)\n"
+        "np.savez(%r, frames=f, states=c.get_states(0, %d), kernel=c.render_kernel_name())\n"
+        "c.close()\n"
+    ) % (helpers.ROOT, str(tmp_path / "scene.npz"), h, w, spp, str(out), n * h * w)
+    automatic = {k: v for k, v in os.environ.items() if k != "REINFOCUS_GENERAL_ONE"}
+    subprocess.check_call([sys.executable, "-c", script], env=automatic)
+    got = np.load(out)
+    assert str(got["kernel"]).startswith("render_general_one_kernel" if cooperative else "render_general_kernel"), got["kernel"]
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+    assert np.array_equal(got["frames"], want) and np.array_equal(got["states"], st)
+
+
 def test_one_shape_worlds_of_both_kinds_take_the_literal_kernel(ctx, oracle):
     """The cooperative kernel is compiled for one kind of shape per launch: a batch whose environments hold one
     rectangle here and one sphere there is rendered by the literal kernel (and equals the oracle as any batch does)."""
