@@ -608,7 +608,7 @@ int render_form(const rf_ctx *ctx, int n, int h, int w, int spp)
 bool fused_step_possible(const rf_ctx *ctx)
 {
     const rf_env_config &h = ctx->env_host;
-    return ctx->env_fused && ctx->env_axis && render_form(ctx, h.n, h.frame_height, h.frame_height, h.spp) == 3;
+    return ctx->env_fused && ctx->env_axis && render_form(ctx, h.n, h.frame_height, h.frame_height, h.spp) != 1;
 }
 
 // enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
@@ -621,7 +621,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     if (rc != RF_OK)
         return rc;
     const int form = render_form(ctx, n, h, w, spp);
-    RF_REQUIRE(!second || (axis && form == 3), "launch_render: no two-pass instance of this kernel");
+    RF_REQUIRE(!second || (axis && form != 1), "launch_render: no two-pass instance of this kernel");
     rf::RenderArgs a;
     a.frames = ctx->d_frames;
     a.states = ctx->d_states;
@@ -746,6 +746,12 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             } else if (axis && form == 1) {
                 hipLaunchKernelGGL((rf::render_kernel_coop<false>), tiles, block, 0, ctx->stream, b);
                 ctx->render_kernel = "render_kernel_coop<false>";
+            } else if (axis && pow2 && second) {
+                hipLaunchKernelGGL((rf::render_kernel<true, true, true>), grid, block, 0, ctx->stream, b);
+                ctx->render_kernel = "render_kernel<true, true, true>";
+            } else if (axis && second) {
+                hipLaunchKernelGGL((rf::render_kernel<true, false, true>), grid, block, 0, ctx->stream, b);
+                ctx->render_kernel = "render_kernel<true, false, true>";
             } else if (axis && pow2) {
                 hipLaunchKernelGGL((rf::render_kernel<true, true>), grid, block, 0, ctx->stream, b);
                 ctx->render_kernel = "render_kernel<true, true>";

@@ -69,55 +69,68 @@ struct RenderArgs {
 };
 
 // AXIS / POW2: exact specialisations, see rf_math.h render_pixel.
-template <bool AXIS, bool POW2>
+// TWO: the fused environment step's form (RenderArgs::count2): the threads of the environments below *count2 render their
+// pixel twice -- the step's frame into frames2, then the scene cam_dyn2 / rect2 of the same slot into frames -- with the
+// RNG state staying in registers in between.
+template <bool AXIS, bool POW2, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4];
 
     const int e = blockIdx.y;
-    if (skip_env(a.rect, e)) // block-uniform, before any barrier
+    if (!TWO && skip_env(a.rect, e)) // block-uniform, before any barrier
         return;
+    const int passes = (TWO && a.env0 + e < *a.count2) ? 2 : 1; // block-uniform
     const int p = blockIdx.x * kBlock + threadIdx.x; // pixel within the env
     const bool live = p < a.hw;
-
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    const int y = p / a.w;
+    const int x = p - y * a.w;
+    const size_t pix = (size_t)e * a.hw + (live ? p : 0);
+    Rng g = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull);
     if (live) {
-        const int y = p / a.w;
-        const int x = p - y * a.w;
-        const size_t pix = (size_t)e * a.hw + p;
-
         const ulonglong2 st = a.states[pix];
-        Rng g = rng_load(st.x, st.y);
-        const PixelEnv env = make_pixel_env(a.cam_dyn + (size_t)e * 9, a.rect + (size_t)e * 2);
-        render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, a.rw64, a.rh64, env, a.cs, a.tab, cr, cg, cb);
-        a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
+        g = rng_load(st.x, st.y);
     }
-
-    // uint8 truncation of float32(colour * scale)   (render.py:244-246)
-    const uint8_t r8 = (uint8_t)(cr * a.scale);
-    const uint8_t g8 = (uint8_t)(cg * a.scale);
-    const uint8_t b8 = (uint8_t)(cb * a.scale);
-
-    const size_t block_px = (size_t)e * a.hw + (size_t)blockIdx.x * kBlock;
-    if ((a.hw & 3) == 0) {
-        // 768 B per block -> LDS -> 192 coalesced dword stores (block base is 4-aligned)
-        uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
-        sb[threadIdx.x * 3 + 0] = r8;
-        sb[threadIdx.x * 3 + 1] = g8;
-        sb[threadIdx.x * 3 + 2] = b8;
-        __syncthreads();
-        const int count = min(kBlock, a.hw - (int)blockIdx.x * kBlock); // multiple of 4
-        const int ndw = count * 3 / 4;
-        if ((int)threadIdx.x < ndw) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(a.frames + block_px * 3);
-            dst[threadIdx.x] = stage[threadIdx.x];
+    for (int pass = 0; pass < passes; ++pass) {
+        const float *const cam = (TWO && pass == 1) ? a.cam_dyn2 : a.cam_dyn;
+        const float *const rect = (TWO && pass == 1) ? a.rect2 : a.rect;
+        uint8_t *const frames = (TWO && pass + 1 < passes) ? a.frames2 : a.frames;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (live) {
+            const PixelEnv env = make_pixel_env(cam + (size_t)e * 9, rect + (size_t)e * 2);
+            render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, a.rw64, a.rh64, env, a.cs, a.tab, cr, cg, cb);
         }
-    } else if (live) {
-        uint8_t *dst = a.frames + (block_px + threadIdx.x) * 3;
-        dst[0] = r8;
-        dst[1] = g8;
-        dst[2] = b8;
+
+        // uint8 truncation of float32(colour * scale)   (render.py:244-246)
+        const uint8_t r8 = (uint8_t)(cr * a.scale);
+        const uint8_t g8 = (uint8_t)(cg * a.scale);
+        const uint8_t b8 = (uint8_t)(cb * a.scale);
+
+        const size_t block_px = (size_t)e * a.hw + (size_t)blockIdx.x * kBlock;
+        if ((a.hw & 3) == 0) {
+            // 768 B per block -> LDS -> 192 coalesced dword stores (block base is 4-aligned)
+            uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+            sb[threadIdx.x * 3 + 0] = r8;
+            sb[threadIdx.x * 3 + 1] = g8;
+            sb[threadIdx.x * 3 + 2] = b8;
+            __syncthreads();
+            const int count = min(kBlock, a.hw - (int)blockIdx.x * kBlock); // multiple of 4
+            const int ndw = count * 3 / 4;
+            if ((int)threadIdx.x < ndw) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(frames + block_px * 3);
+                dst[threadIdx.x] = stage[threadIdx.x];
+            }
+            if (TWO && pass + 1 < passes)
+                __syncthreads(); // (the next pass writes the stage again)
+        } else if (live) {
+            uint8_t *dst = frames + (block_px + threadIdx.x) * 3;
+            dst[0] = r8;
+            dst[1] = g8;
+            dst[2] = b8;
+        }
     }
+    if (live)
+        a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
 }
 
 // ---------------------------------------------------------------------------

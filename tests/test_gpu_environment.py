@@ -111,10 +111,13 @@ def test_vector_environment_steps_and_auto_resets(oracle):
 # auto-reset launch by the count ("count-sized": rf_env_step_begin + rf_env_step_end, what a sharded environment
 # uses).  The context reads the knobs at rf_create.
 STEP_BRANCHES = {"fused-graph": {}, "fused": {"REINFOCUS_ENV_GRAPH": "0"},
+                 # (the two-pass form of the kernel without cooperative tails: what launches of few blocks take)
+                 "fused-graph, plain kernel": {"REINFOCUS_RENDER_COOP": "0"},
                  "graph": {"REINFOCUS_ENV_FUSED": "0"},
                  "one-sync": {"REINFOCUS_ENV_FUSED": "0", "REINFOCUS_ENV_GRAPH": "0"},
                  "count-sized": {"REINFOCUS_ENV_FUSED": "0", "REINFOCUS_ENV_ONE_SYNC_MAX": "0"}}
 FIRST_STEP_BRANCH = {"fused-graph": "fused", "graph": "one-sync"}  # (a graph is captured from the second step on)
+BRANCH_NAME = {"fused-graph, plain kernel": "fused-graph"}
 
 
 @pytest.mark.parametrize("branch", list(STEP_BRANCHES))
@@ -150,8 +153,10 @@ def test_device_resident_step_equals_host_harness(n, height, spp, steps, branch,
         assert np.array_equal(host._state, dev._state)
         resets += int(ch.sum())
         # (a graph is captured from the second step on, when every buffer has its final size)
-        assert dev._ctx.env_last_step_branch() == (FIRST_STEP_BRANCH.get(branch, branch) if step == 0 else branch)
+        name = BRANCH_NAME.get(branch, branch)
+        assert dev._ctx.env_last_step_branch() == (FIRST_STEP_BRANCH.get(name, name) if step == 0 else name)
     assert resets > 0
+    assert ("plain" in branch) == dev._ctx.render_kernel_name().startswith("render_kernel<")
     # both initializers consumed the same number of draws
     assert host._initializer._generator.bit_generator.state == dev._initializer._generator.bit_generator.state
     host.close()
@@ -605,8 +610,8 @@ def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
 
 def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
     """The library's own choice for launches of few blocks (rf_abi.hip few_blocks: the reference's default single
-    environment among them): the kernel without cooperative tails, and with it the schedules of separate launches -- a device-resident
-    environment of 3 x 64 x 64 at 8 samples replays its step as a hipGraph of them, equal to the numpy glue."""
+    environment among them): the kernel without cooperative tails, in its two-pass form inside the fused step -- a
+    device-resident environment of 3 x 64 x 64 at 8 samples, equal to the numpy glue."""
     from reinfocus_amd.environments import harness
 
     monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
@@ -618,8 +623,8 @@ def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
         actions = rng.integers(0, 13, 3)
         for x, y in zip(host.step(actions)[:4], dev.step(actions)[:4]):
             assert np.array_equal(x, y)
-        assert dev._ctx.env_last_step_branch() == ("one-sync" if step == 0 else "graph")
-        assert dev._ctx.render_kernel_name().startswith("render_kernel<")
+        assert dev._ctx.env_last_step_branch() == ("fused" if step == 0 else "fused-graph")
+        assert dev._ctx.render_kernel_name() == "render_kernel<true, true, true>"  # (its two-pass form)
     assert np.array_equal(host._state, dev._state)
     host.close()
     dev.close()
