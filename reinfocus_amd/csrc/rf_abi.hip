@@ -592,9 +592,9 @@ struct SecondPass {
 // and the kernel without them (render_kernel<AXIS, POW2>: one pixel per thread, rejection loops inside the wave) is the
 // fastest form -- 1 x 300^2 x 100: 687 us per step with three pixels per thread, 419 with one and cooperative tails, 289
 // without them; 4 environments 863 / 646 / 563.  Three pixels per thread win from about 650 000 pixels per launch on (10
-// environments of 300^2 or of 256^2, 40 of 128^2: profiles/r04_ab.txt section 18).  Below 8 samples per pixel the
-// launches saved by the fused step weigh more than a sample's latency.
-bool few_blocks(uint64_t n, uint64_t h, uint64_t w, int spp) { return n * h * w <= 650000 && spp >= 8; }
+// environments of 300^2 or of 256^2, 40 of 128^2: profiles/r04_ab.txt section 18), at any number of samples (the
+// kernel has a two-pass form of its own, so the fused step's few launches serve both).
+bool few_blocks(uint64_t n, uint64_t h, uint64_t w, int spp) { return n * h * w <= 650000; }
 
 // which render kernel a launch takes: 3 = three pixels per thread with cooperative tails (render_kernel_coop2 and its
 // strip form), 1 = one pixel per thread with them (render_kernel_coop), 0 = without them (render_kernel)

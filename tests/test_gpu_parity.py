@@ -463,10 +463,10 @@ def test_delayed_waves_change_nothing(oracle, tmp_path, h):
 
 
 @pytest.mark.parametrize("n,h,spp,three", [(1, 300, 8, False), (7, 300, 8, False), (8, 300, 8, True), (9, 256, 9, False), (10, 256, 8, True),
-                                           (2, 128, 7, True), (36, 128, 16, False)])
+                                           (2, 128, 3, False), (45, 128, 2, True), (36, 128, 16, False)])
 def test_few_blocks_take_one_pixel_per_thread(oracle, tmp_path, n, h, spp, three):
     """Without REINFOCUS_RENDER_SETS the library picks the kernel by the size of the launch: up to 650 000 pixels (about
-    850 blocks of three pixels per thread) at 8 or more samples per pixel -- the reference's own default, one environment
+    850 blocks of three pixels per thread) -- the reference's own default, one environment
     of 300 x 300 at 100 samples, is such a launch -- render with the kernel without cooperative tails (render_kernel: one
     pixel per thread, no barriers: such launches are bound by a sample's latency), everything else with three pixels per
     thread.  Same frames, same RNG states, either way."""
