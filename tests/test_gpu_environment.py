@@ -563,7 +563,8 @@ def test_planned_step_equals_the_whole_step(fused, monkeypatch):
 
 
 @pytest.mark.parametrize("build,height", [("libreinfocus_skew.so", 128), ("libreinfocus_skew.so", 100),
-                                          ("libreinfocus_cap32.so", 128)])
+                                          ("libreinfocus_cap32.so", 128), ("libreinfocus_skew.so", 132),
+                                          ("libreinfocus_cap32.so", 164)])  # (132, 164: the strip kernel)
 def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
     """The two-pass instance of the render kernel (the fused step's: a block renders its tile, then the tile of the
     environment that takes its slot in the auto-reset's compacted set) under the test builds that
