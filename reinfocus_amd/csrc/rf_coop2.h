@@ -1,10 +1,15 @@
 // rf_coop2.h -- render_kernel_coop2<POW2, LENS, WX, WW>: the default render kernel.
 //
-// Same arithmetic, same pixel <-> RNG-state mapping and the same idea as render_kernel_coop
-// (rf_kernels.h) -- lanes whose rejection loop is not done after their in-wave attempt hand their
-// RNG state to a packed list in LDS that full waves finish -- organised for gfx950 (every choice
-// below was measured; the rejected alternatives are in git history, DESIGN.md 4.1 and
-// profiles/r0*_ab.txt, not in this file):
+// Same arithmetic and the same pixel <-> RNG-state mapping as render_kernel (rf_render.h), with the rejection
+// loops made block-cooperative.  In a wave whose 64 pixels all hit the target the sphere loop of physics.py:31-44
+// runs for max-over-lanes = ~6.5 trips although a lane needs 1.9 on average (disc: 3.5 against 1.27).  Here every
+// lane makes its first attempts in its own wave; the lanes still looking hand their RNG state to a packed list in
+// LDS that full waves finish, and take the advanced state and the accepted draws back.  Which lane executes an
+// attempt does not matter -- the stream of a pixel is advanced by exactly the same draws -- so results are
+// bit-identical to render_kernel (and to the oracle).  All 256 threads of a block run the sample loop in lockstep
+// (dead threads of a partial block included) so that every barrier is reached by every thread.
+// Organised for gfx950 (every choice below was measured; the rejected alternatives are in git history,
+// profiles/HISTORY.md and profiles/r0*_ab.txt, not in this file):
 //
 //  * kSets = 3 pixels per thread (tile 128 x 6: a thread owns (x, y + 2 j), j < 3): every wave does
 //    the in-wave work of three pixel sets between two barriers and one cooperative call serves all
@@ -52,12 +57,60 @@
 //   Checked two ways: tests/test_sync_model.py writes this protocol down array by array and verifies, for every
 //   combination of call outcomes, that no two conflicting accesses of different waves share a barrier epoch (and that
 //   the round-3 form fails that check); tests/test_gpu_parity.py::test_delayed_waves_change_nothing runs a build
-//   whose waves are delayed at exactly these points (RF_TEST_SKEW, rf_kernels.h).
+//   whose waves are delayed at exactly these points (RF_TEST_SKEW below).
 #pragma once
 
-#include "rf_kernels.h"
+#include <type_traits>
+
+#include "rf_render.h"
 
 namespace rf {
+
+// The LDS arrays of a cooperative call.  `state` is doubled because a fast wave parks the stragglers of the next
+// call while a slow one is still collecting; the draws are only written after the next call's first barrier.
+template <int N>
+struct CoopLdsT {
+    uint4 state[2][N];
+    uint4 words4[N];
+    uint2 words2[N];
+    uint16_t owner[N]; // original slot of a re-packed entry
+    int cnt[2];
+    int cnt2;          // entries in the second round
+};
+
+// RF_TEST_SKEW (tests/gpucheck/libreinfocus_skew.so, tests/test_gpu_parity.py; used by the cooperative calls
+// below and by rf_general_one.h): one wave of every block -- a different
+// one from call to call -- sleeps ~8 000 cycles at each point where a cooperative call is ordered against the next
+// one by a barrier alone: before it reads the counter after B1, before thread 0's resets, before the collect reads.
+// With the ordering right the sleeps change nothing (frames and RNG states stay bit-identical to the oracle); the
+// round-3 form of the call -- no B4, one counter -- produces wrong frames under them (profiles/r04_ab.txt section 7).
+#ifndef RF_TEST_SKEW
+#define RF_TEST_SKEW 0
+#endif
+__device__ __forceinline__ void test_skew(int tid, int turn)
+{
+#if RF_TEST_SKEW
+    if (((tid >> 6) & 3) == (turn & 3)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_s_sleep(127); // 8 x 127 x 64 cycles
+    }
+#else
+    (void)tid;
+    (void)turn;
+#endif
+}
+
+// Pixel <-> lane mapping of the cooperative kernel: a wave owns kWaveW x kWaveH pixels and a
+// block kWavesX x (4 / kWavesX) waves.  The mapping only changes which thread owns a pixel,
+// not the pixel's RNG stream, so it is a pure scheduling knob (a wave always reads / writes
+// whole 128-B lines of RNG state as long as kWaveW >= 8).  Measured at the headline config
+// (tools sweep, round 1): 32 x 2 pixel waves side by side (128 x 2 blocks) are 8 % faster
+// than 64 x 1 rows and than squarer tiles.
+constexpr int kWaveW = 32, kWaveH = 64 / kWaveW;
+constexpr int kWavesX = 4, kWavesY = (kBlock / 64) / kWavesX;
+constexpr int kTileW = kWavesX * kWaveW, kTileH = kWavesY * kWaveH;
+
 
 constexpr int kSets = 3;      // pixels per thread (2 / 3 / 4: 133 / 138 / 114 G samples/s)
 constexpr int kSetsOcc = 7;   // waves per SIMD the register allocator is held to
@@ -405,8 +458,14 @@ __device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLd
         asm volatile("" : "+s"(kernarg), "+s"(e), "+s"(block_x));
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < kBlock2);
-        // (the first argument: offset 0 of the segment; constant address space: scalar loads)
+        // (the first argument: offset 0 of the segment; constant address space: scalar loads.  CONTRACT: RenderArgs is
+        // the kernel's first and only explicit argument, passed by value -- see the static_asserts at the __global__ entry
+        // points below; the delayed-waves test build also compares what it read with the argument itself)
         a_pass = *(const RenderArgs *)(const __attribute__((address_space(4))) RenderArgs *)kernarg;
+#if RF_TEST_SKEW
+        if (a_pass.hw != a_in.hw || a_pass.frames != a_in.frames || a_pass.states != a_in.states || a_pass.spp != a_in.spp)
+            __builtin_trap();
+#endif
     }
     const RenderArgs &a = TWO ? a_pass : a_in;
     const float *const scene_cam = (TWO && pass == 1) ? a.cam_dyn2 : a.cam_dyn;
@@ -423,7 +482,10 @@ __device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLd
     const int tile_index = block_x - (REGION == 2 ? a.main_tiles : 0);
     const int tiles_x = (x_end - x_origin + tAllW - 1) / tAllW;
     const int tile_y = tile_index / tiles_x, tile_x = tile_index - tile_y * tiles_x;
-    const bool mirror = REGION == 0 && (2 * tile_x + 1) * tTileW > a.w; // see render_kernel_coop
+    // Tiles in the right half of the frame place their waves right to left, so that wave 0 -- which finishes the
+    // cooperative tails -- is the outermost wave on both sides of the (centred) target: the one with the fewest hit
+    // lanes of its own (+2.6 % measured).
+    const bool mirror = REGION == 0 && (2 * tile_x + 1) * tTileW > a.w;
 
     // Pixel geometry of a thread.  Set j covers the rows tTileH * j further down.  All of it is
     // cheap to derive from the thread index, and the sample loop derives it afresh every
@@ -653,9 +715,18 @@ __device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLd
   } // pass
 }
 
+// (two-pass tile code re-reads the kernel arguments from offset 0 of the kernarg segment: a kernel that uses it takes
+// exactly one argument, a RenderArgs by value)
+template <class F>
+struct takes_render_args_only : std::false_type {};
+template <>
+struct takes_render_args_only<void (*)(RenderArgs)> : std::true_type {};
+
 template <bool POW2, int LENS, int WX = kWavesX, int WW = kWaveW, bool TWO = false>
 __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderArgs a_in)
 {
+    static_assert(takes_render_args_only<decltype(&render_kernel_coop2<POW2, LENS, WX, WW, TWO>)>::value,
+                  "render_tile_coop2<.., TWO> reads RenderArgs from offset 0 of the kernarg segment");
     __shared__ CoopLds2 lds;
     // colour accumulators of the first kColourLds pixel sets live in LDS (one read-modify-write
     // per sample and channel, off the vector ALU) to keep the kernel inside its VGPR budget
@@ -673,6 +744,8 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2(RenderA
 template <int LENS, int MAIN_WX = 2>
 __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2_strip(RenderArgs a_in)
 {
+    static_assert(takes_render_args_only<decltype(&render_kernel_coop2_strip<LENS, MAIN_WX>)>::value,
+                  "render_tile_coop2<.., TWO> reads RenderArgs from offset 0 of the kernarg segment");
     __shared__ CoopLds2 lds;
     __shared__ float lds_colour[kColourLds][3][kBlock2];
     if (skip_env(a_in.rect, blockIdx.y)) // (slots a launch for all n environments has to leave alone: never a real rectangle)

@@ -32,7 +32,7 @@
 #pragma once
 
 #include "rf_coop2.h"
-#include "rf_kernels.h"
+#include "rf_general_kernels.h"
 
 namespace rf {
 

@@ -596,7 +596,7 @@ RF_HD float pixel_coord_pow2_64(float xf, float xi64, float inv_w)
 
 // ---------------------------------------------------------------------------
 // one pixel of FastRenderer._device_render (render.py:210-246): spp samples
-// accumulated in f32.  Shared verbatim by the gfx950 kernel (rf_kernels.h) and the
+// accumulated in f32.  Shared verbatim by the gfx950 kernel (rf_render.h) and the
 // CPU-side simulation used only by tests (tests/hostsim).
 //
 // AXIS: the camera frame is the canonical one FastCameras() always produces

@@ -455,11 +455,9 @@ def test_delayed_waves_change_nothing(oracle, tmp_path, h):
     d = helpers.pack_scene(np.array([5.5, 7.0, 9.5], dtype=np.float32), np.array([5.5, 9.0, 6.0], dtype=np.float32))
     states = oracle.seed_states(n * h * h, 0)
     want = oracle.render(d[0], d[1], h, h, spp, states)  # (advances `states` in place)
-    # render_kernel_coop2 (three pixels per thread), and the one-pixel cooperative kernel behind REINFOCUS_RENDER_SETS=1
-    for overrides in ({}, {"REINFOCUS_RENDER_SETS": "1"}):
-        frames, final = _render_in_child(tmp_path, d, n, h, spp, dict(overrides, REINFOCUS_HIP_LIB=so))
-        assert np.array_equal(frames, want), overrides
-        assert np.array_equal(final, states), overrides
+    frames, final = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_HIP_LIB": so})
+    assert np.array_equal(frames, want)
+    assert np.array_equal(final, states)
 
 
 @pytest.mark.parametrize("n,h,spp,three", [(1, 300, 8, False), (7, 300, 8, False), (8, 300, 8, True), (9, 256, 9, False), (10, 256, 8, True),
@@ -481,13 +479,12 @@ def test_few_blocks_take_one_pixel_per_thread(oracle, tmp_path, n, h, spp, three
     assert np.array_equal(frames, want) and np.array_equal(final, states)
 
 
-@pytest.mark.parametrize("overrides", [{"REINFOCUS_RENDER_SETS": "1"}, {"REINFOCUS_RENDER_COOP": "0"}],
-                         ids=["one-pixel-coop", "no-coop"])
 @pytest.mark.parametrize("h", [64, 50])
-def test_fallback_render_kernels_match_oracle(oracle, tmp_path, overrides, h):
-    """The kernels behind the switches (render_kernel_coop, render_kernel<AXIS, *>) stay
-    bit-identical to the oracle: power-of-two and other frame sizes."""
+def test_fallback_render_kernel_matches_oracle(oracle, tmp_path, h):
+    """The kernel behind REINFOCUS_RENDER_COOP=0 (render_kernel<AXIS, *> at every size) stays bit-identical to the
+    oracle: power-of-two and other frame sizes."""
     n, spp = 4, 5
+    overrides = {"REINFOCUS_RENDER_COOP": "0"}
     rng = np.random.default_rng(12)
     d = helpers.pack_scene(*helpers.random_scene(rng, n))
     frames, final = _render_in_child(tmp_path, d, n, h, spp, overrides)
