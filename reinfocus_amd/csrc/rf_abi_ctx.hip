@@ -110,6 +110,22 @@ void lens_split(rf::CamStatic &cs)
     cs.lens_f32 = it->second ? 1 : 0;
 }
 
+int seed_range(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t seed, uint64_t first_state_index)
+{
+    RF_REQUIRE(first + count <= ctx->n_states, "seed_range: [%llu, %llu) exceeds %llu states", (unsigned long long)first,
+               (unsigned long long)(first + count), (unsigned long long)ctx->n_states);
+    const rf::S128 s0 = rf::h_splitmix(seed);
+    const uint64_t per_wave = 64ull * rf::kSeedRun;
+    const uint64_t waves = (count + per_wave - 1) / per_wave;
+    const uint64_t blocks = (waves * 64 + rf::kBlock - 1) / rf::kBlock;
+    RF_REQUIRE(blocks < (1ull << 31), "rf_seed: too many states for one launch");
+    hipLaunchKernelGGL(rf::seed_kernel, dim3((unsigned)blocks), dim3(rf::kBlock), 0, ctx->stream, ctx->d_states + first,
+                       (unsigned long long)count, (unsigned long long)first_state_index, make_ulonglong2(s0.s0, s0.s1),
+                       ctx->d_mats);
+    RF_HIP(hipGetLastError());
+    return RF_OK;
+}
+
 } // namespace rfh
 
 extern "C" {
@@ -274,17 +290,7 @@ int rf_seed(rf_ctx *ctx, uint64_t n_states, uint64_t seed, uint64_t first_state_
         RF_HIP(hipMalloc((void **)&ctx->d_states, n_states * sizeof(ulonglong2)));
         ctx->n_states = n_states;
     }
-    const rf::S128 s0 = rf::h_splitmix(seed);
-    const uint64_t per_wave = 64ull * rf::kSeedRun;
-    const uint64_t waves = (n_states + per_wave - 1) / per_wave;
-    const uint64_t blocks = (waves * 64 + rf::kBlock - 1) / rf::kBlock;
-    RF_REQUIRE(blocks < (1ull << 31), "rf_seed: too many states for one launch");
-    hipLaunchKernelGGL(rf::seed_kernel, dim3((unsigned)blocks), dim3(rf::kBlock), 0, ctx->stream,
-                       ctx->d_states, (unsigned long long)n_states,
-                       (unsigned long long)first_state_index, make_ulonglong2(s0.s0, s0.s1),
-                       ctx->d_mats);
-    RF_HIP(hipGetLastError());
-    return RF_OK;
+    return rfh::seed_range(ctx, 0, n_states, seed, first_state_index);
 }
 
 int rf_num_states(rf_ctx *ctx, uint64_t *n_states)

@@ -2,6 +2,8 @@
 // rf_general_kernels.h, rf_general_one.h)
 #include "rf_host.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -64,7 +66,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             RF_REQUIRE(types[(size_t)e * most + i] == 0 || types[(size_t)e * most + i] == 1,
                        "rf_render_general: unknown shape type");
     }
-    int rc = seed_zero_cached(ctx, (uint64_t)n * h * w); // render.py:115: fresh seed-0 states per call
+    const uint64_t hw64 = (uint64_t)h * (uint64_t)w, pixels = (uint64_t)n * hw64;
+    int rc = seed_zero_cached(ctx, pixels); // render.py:115: fresh seed-0 states per call
     if (rc != RF_OK)
         return rc;
     rc = ensure_frames(ctx, n, h, w);
@@ -73,28 +76,60 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     std::vector<rf::GeneralCamera> cams((size_t)n);
     for (int e = 0; e < n; ++e)
         cams[(size_t)e] = rf::general_camera(cameras + (size_t)e * 19);
-    const size_t b_cam = (size_t)n * sizeof(rf::GeneralCamera), b_par = (size_t)n * most * width * sizeof(float),
-                 b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t);
-    // worlds of one rectangle per environment (and frames the quick pixel coordinates are proven for) take the cooperative
-    // kernel of rf_general_one.h; everything else the literal one
-    // worlds of exactly one shape per environment, the same kind in all of them: the cooperative kernel (rf_general_one.h)
-    bool one_shape = ctx->general_one && h <= 4096 && w <= 4096 && width >= 7;
-    const bool one_sphere = one_shape && n > 0 && types[0] == 0;
-    // ... for launches that fill the device: the notebooks' one or two environments are a few hundred blocks, bound by the
-    // latency of a sample, and there the literal kernel (one pixel per thread, no barriers) is up to three times faster
-    // (1 x 300^2 x 100: 0.35 ms against 1.02); the cooperative kernel wins from about 2 M pixels per launch on with a
-    // rectangle, 3 M with a sphere (profiles/r04_ab.txt section 19)
-    if (one_shape && !ctx->general_one_always && (uint64_t)n * (uint64_t)h * (uint64_t)w <= (one_sphere ? 3000000u : 2000000u))
-        one_shape = false;
+
+    // Which kernel (all bit-identical):
+    //  * kOne: worlds of exactly one shape per environment, the same kind in all of them, in launches that fill the device
+    //    (more than 2 M pixels with a rectangle, 3 M with a sphere): the cooperative kernel of rf_general_one.h.  The
+    //    notebooks' one or two environments are a few hundred blocks, bound by the latency of a sample, where a kernel
+    //    without barriers is up to three times faster (profiles/r04_ab.txt section 19).
+    //  * kDense: one or two shapes in every environment, cameras with simple axes and a lens radius whose float32 offset is
+    //    exact, frames the quick pixel coordinates are proven for: the float32 kernel with abstentions (rf_general_dense.h).
+    //  * kLiteral: everything else.
+    enum { kLiteral, kOne, kDense } kind = kLiteral;
+    const bool quick_frame = h <= 4096 && w <= 4096;
+    bool uniform_count = most <= 2;
+    for (int e = 0; uniform_count && e < n; ++e)
+        uniform_count = sizes[e] == most;
+    const bool one_sphere = types[0] == 0;
+    bool one_shape = ctx->general_one && quick_frame && uniform_count && most == 1 &&
+                     (ctx->general_one_always || pixels > (one_sphere ? 3000000u : 2000000u));
     for (int e = 0; one_shape && e < n; ++e)
-        one_shape = sizes[e] == 1 && types[(size_t)e * most] == (one_sphere ? 0 : 1);
-    // environments per launch: the grid's y limit, and (cooperative kernel) pixel indices of the fix-up list in 32 bits
-    const uint64_t hw64 = (uint64_t)h * (uint64_t)w;
-    const int chunk = one_shape ? (int)std::min<uint64_t>(65535, 0xFFFFFFFFull / hw64) : 65535;
-    const size_t b_redo = one_shape ? 256 + (size_t)std::min<uint64_t>((uint64_t)n, (uint64_t)chunk) * hw64 * sizeof(unsigned) : 0;
-    const size_t o_par = (b_cam + 255) & ~(size_t)255, o_typ = o_par + ((b_par + 255) & ~(size_t)255),
-                 o_siz = o_typ + ((b_typ + 255) & ~(size_t)255), o_redo = o_siz + ((b_siz + 255) & ~(size_t)255),
-                 total = o_redo + b_redo;
+        one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
+    if (one_shape) {
+        kind = kOne;
+    } else if (ctx->general_dense && quick_frame && uniform_count) {
+        bool simple = true;
+        for (int e = 0; simple && e < n; ++e) {
+            rf::CamStatic probe{};
+            probe.lens_radius = cams[(size_t)e].lens_radius;
+            lens_split(probe); // (remembered per radius)
+            simple = probe.lens_f32 != 0 && rf::camera_axes_simple(cams[(size_t)e]);
+        }
+        if (simple)
+            kind = kDense;
+    }
+    const bool listed = kind != kLiteral;
+
+    // environments per launch: the grid's y limit, and (kernels with a fix-up list) pixel indices in 32 bits
+    const int chunk = listed ? (int)std::min<uint64_t>(65535, 0xFFFFFFFFull / hw64) : 65535;
+    const int n_chunks = (n + chunk - 1) / chunk;
+    // the fix-up list: about one pixel in 10^3 abstains (one in 10^2 at 100 samples); a launch that abstains more often
+    // than the list holds is rendered again by the literal kernel (below)
+    const uint64_t chunk_pixels = std::min<uint64_t>((uint64_t)n, (uint64_t)chunk) * hw64;
+    uint64_t cap = std::min<uint64_t>(chunk_pixels, std::max<uint64_t>(65536, chunk_pixels / 16));
+    if (const char *v = getenv("REINFOCUS_GENERAL_REDO_CAP")) { // (tests: the overflow path at small sizes)
+        char *end = nullptr;
+        const long forced = strtol(v, &end, 10);
+        if (end != v && forced >= 1)
+            cap = std::min<uint64_t>(chunk_pixels, (uint64_t)forced);
+    }
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_cam = (size_t)n * sizeof(rf::GeneralCamera), b_par = (size_t)n * most * width * sizeof(float),
+                 b_typ = (size_t)n * most * sizeof(int32_t), b_siz = (size_t)n * sizeof(int32_t),
+                 b_shp = kind == kDense ? (size_t)n * most * sizeof(rf::ShapeConst) : 0,
+                 b_cnt = listed ? (size_t)n_chunks * sizeof(unsigned) : 0, b_lst = listed ? (size_t)cap * sizeof(unsigned) : 0;
+    const size_t o_par = pad(b_cam), o_typ = o_par + pad(b_par), o_siz = o_typ + pad(b_typ), o_shp = o_siz + pad(b_siz),
+                 o_cnt = o_shp + pad(b_shp), o_lst = o_cnt + pad(b_cnt), total = o_lst + pad(b_lst);
     if (total > ctx->general_scratch_bytes) { // grown on demand, owned by the ctx
         RF_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->general_scratch)
@@ -105,93 +140,157 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
         ctx->general_scratch_bytes = total;
     }
     char *const scratch = (char *)ctx->general_scratch;
-    hipError_t he = hipMemcpyAsync(scratch, cams.data(), b_cam, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_typ, types, b_typ, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(scratch + o_siz, sizes, b_siz, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) {
-        rf::GeneralArgs a;
-        a.frames = ctx->d_frames;
-        a.states = ctx->d_states;
-        a.cameras = (const rf::GeneralCamera *)scratch;
-        a.params = (const float *)(scratch + o_par);
-        a.types = (const int32_t *)(scratch + o_typ);
-        a.sizes = (const int32_t *)(scratch + o_siz);
-        a.n = n;
-        a.h = h;
-        a.w = w;
-        a.spp = spp;
-        a.hw = h * w;
-        a.most = most;
-        a.width = width;
-        a.scale = (float)(255.0 / (double)spp);
-        const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
-        const bool pow2 = is_pow2(h) && is_pow2(w);
+    std::vector<rf::ShapeConst> shapes;
+    if (kind == kDense) {
+        shapes.resize((size_t)n * most);
+        for (size_t i = 0; i < shapes.size(); ++i)
+            shapes[i] = rf::shape_const(params + i * width, width, types[i]);
+    }
+    RF_HIP(hipMemcpyAsync(scratch, cams.data(), b_cam, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipMemcpyAsync(scratch + o_typ, types, b_typ, hipMemcpyHostToDevice, ctx->stream));
+    RF_HIP(hipMemcpyAsync(scratch + o_siz, sizes, b_siz, hipMemcpyHostToDevice, ctx->stream));
+    if (b_shp)
+        RF_HIP(hipMemcpyAsync(scratch + o_shp, shapes.data(), b_shp, hipMemcpyHostToDevice, ctx->stream));
+    if (b_cnt)
+        RF_HIP(hipMemsetAsync(scratch + o_cnt, 0, b_cnt, ctx->stream));
+
+    rf::GeneralArgs a;
+    a.frames = ctx->d_frames;
+    a.states = ctx->d_states;
+    a.cameras = (const rf::GeneralCamera *)scratch;
+    a.params = (const float *)(scratch + o_par);
+    a.types = (const int32_t *)(scratch + o_typ);
+    a.sizes = (const int32_t *)(scratch + o_siz);
+    a.n = n;
+    a.h = h;
+    a.w = w;
+    a.spp = spp;
+    a.hw = h * w;
+    a.most = most;
+    a.width = width;
+    a.scale = (float)(255.0 / (double)spp);
+    const int gx = (a.hw + rf::kBlock - 1) / rf::kBlock;
+    const bool pow2 = is_pow2(h) && is_pow2(w);
+    auto chunk_args = [&](int e0, int ne) {
+        rf::GeneralArgs b = a;
+        b.frames = a.frames + (size_t)e0 * a.hw * 3;
+        b.states = a.states + (size_t)e0 * a.hw;
+        b.cameras = a.cameras + (size_t)e0;
+        b.params = a.params + (size_t)e0 * most * width;
+        b.types = a.types + (size_t)e0 * most;
+        b.sizes = a.sizes + e0;
+        b.n = ne;
+        return b;
+    };
+    auto launch_literal = [&](const rf::GeneralArgs &b) {
+        if (pow2)
+            hipLaunchKernelGGL(rf::render_general_kernel<true>, dim3(gx, b.n), dim3(rf::kBlock), 0, ctx->stream, b);
+        else
+            hipLaunchKernelGGL(rf::render_general_kernel<false>, dim3(gx, b.n), dim3(rf::kBlock), 0, ctx->stream, b);
+    };
+    {
         Timed timed(ctx, &ctx->ev_render);
-        for (int e0 = 0; e0 < n && he == hipSuccess; e0 += chunk) {
-            const int ne = (n - e0) < chunk ? (n - e0) : chunk;
-            rf::GeneralArgs b = a;
-            b.frames = a.frames + (size_t)e0 * a.hw * 3;
-            b.states = a.states + (size_t)e0 * a.hw;
-            b.cameras = a.cameras + (size_t)e0;
-            b.params = a.params + (size_t)e0 * most * width;
-            b.types = a.types + (size_t)e0 * most;
-            b.sizes = a.sizes + e0;
-            b.n = ne;
-            if (one_shape) {
-                rf::GeneralOneArgs d;
-                d.g = b;
-                d.redo_count = (unsigned *)(scratch + o_redo);
-                d.redo_list = (unsigned *)(scratch + o_redo + 256);
-                d.w64 = (double)w;
-                d.h64 = (double)h;
-                d.rw64 = 1.0 / (double)w;
-                d.rh64 = 1.0 / (double)h;
-                d.inv_w = 1.0f / (float)w;
-                d.inv_h = 1.0f / (float)h;
-                he = hipMemsetAsync(d.redo_count, 0, sizeof(unsigned), ctx->stream);
-                if (he != hipSuccess)
-                    break;
-                // tiles of 128 x 6 or of 64 x 12, whichever leaves fewer dead columns
-                const bool narrow = ((w + 63) / 64) * 64 < ((w + 127) / 128) * 128;
-                const dim3 tiles(narrow ? (unsigned)(((w + 63) / 64) * ((h + 4 * rf::kSets - 1) / (4 * rf::kSets)))
-                                        : (unsigned)(((w + 127) / 128) * ((h + 2 * rf::kSets - 1) / (2 * rf::kSets))), ne);
-                const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
-                const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
+        for (int c = 0; c < n_chunks; ++c) {
+            const int e0 = c * chunk, ne = std::min(chunk, n - e0);
+            const rf::GeneralArgs b = chunk_args(e0, ne);
+            if (!listed) {
+                launch_literal(b);
+                ctx->render_kernel = pow2 ? "render_general_kernel<true>" : "render_general_kernel<false>";
+                continue;
+            }
+            rf::GeneralOneArgs d;
+            d.g = b;
+            d.redo_count = (unsigned *)(scratch + o_cnt) + c;
+            d.redo_list = (unsigned *)(scratch + o_lst);
+            d.redo_cap = (unsigned)cap;
+            d.shapes = (const rf::ShapeConst *)(scratch + o_shp) + (size_t)e0 * most;
+            d.w64 = (double)w;
+            d.h64 = (double)h;
+            d.rw64 = 1.0 / (double)w;
+            d.rh64 = 1.0 / (double)h;
+            d.inv_w = 1.0f / (float)w;
+            d.inv_h = 1.0f / (float)h;
+            const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
+            const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
+            if (kind == kDense) {
+                // 16 x 16 tiles (waves of 8 x 8 pixels) unless they pad the frame much more than 256-pixel runs do (frames
+                // narrower or lower than a tile)
+                const uint64_t tiles = (uint64_t)((w + 15) / 16) * (uint64_t)((h + 15) / 16);
+                const bool tiled = tiles * 256 * 100 <= (uint64_t)gx * 256 * 115;
+                const uint64_t per_env = tiled ? tiles : (uint64_t)gx;
+                RF_REQUIRE(per_env * (uint64_t)ne < (1ull << 31), "rf_render_general: too many blocks for one launch");
+                const dim3 grid_t((unsigned)(per_env * (uint64_t)ne)); // (the environment is the fastest index)
+#define RF_LAUNCH_DENSE_T(P, NS, T)                                                                                      \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((rf::render_general_dense_kernel<P, NS, T>), grid_t, dim3(rf::kBlock), 0, ctx->stream, d);   \
+        hipLaunchKernelGGL(rf::render_general_fixup_kernel<P>, fix, dim3(rf::kBlock), 0, ctx->stream, d);             \
+        ctx->render_kernel = "render_general_dense_kernel<" #P ", " #NS ", " #T ">";                                   \
+    } while (0)
+#define RF_LAUNCH_DENSE(P, NS)                                                                                          \
+    do {                                                                                                               \
+        if (tiled) RF_LAUNCH_DENSE_T(P, NS, true);                                                                     \
+        else RF_LAUNCH_DENSE_T(P, NS, false);                                                                          \
+    } while (0)
+                if (pow2 && most == 1) RF_LAUNCH_DENSE(true, 1);
+                else if (pow2) RF_LAUNCH_DENSE(true, 2);
+                else if (most == 1) RF_LAUNCH_DENSE(false, 1);
+                else RF_LAUNCH_DENSE(false, 2);
+#undef RF_LAUNCH_DENSE
+#undef RF_LAUNCH_DENSE_T
+                continue;
+            }
+            // tiles of 128 x 6 or of 64 x 12, whichever leaves fewer dead columns
+            const bool narrow = ((w + 63) / 64) * 64 < ((w + 127) / 128) * 128;
+            const uint64_t tiles_one = narrow ? (uint64_t)((w + 63) / 64) * (uint64_t)((h + 4 * rf::kSets - 1) / (4 * rf::kSets))
+                                              : (uint64_t)((w + 127) / 128) * (uint64_t)((h + 2 * rf::kSets - 1) / (2 * rf::kSets));
+            const dim3 tiles((unsigned)(tiles_one * (uint64_t)ne)); // (one-dimensional, the environment fastest)
 #define RF_LAUNCH_ONE(P, S, WXV)                                                                                          \
     do {                                                                                                               \
         hipLaunchKernelGGL((rf::render_general_one_kernel<P, S, WXV>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);   \
         hipLaunchKernelGGL(rf::render_general_fixup_kernel<P>, fix, dim3(rf::kBlock), 0, ctx->stream, d);             \
         ctx->render_kernel = "render_general_one_kernel<" #P ", " #S ", " #WXV ">";                                    \
     } while (0)
-                if (one_sphere && pow2 && narrow) RF_LAUNCH_ONE(true, true, 2);
-                else if (one_sphere && pow2) RF_LAUNCH_ONE(true, true, 4);
-                else if (one_sphere && narrow) RF_LAUNCH_ONE(false, true, 2);
-                else if (one_sphere) RF_LAUNCH_ONE(false, true, 4);
-                else if (pow2 && narrow) RF_LAUNCH_ONE(true, false, 2);
-                else if (pow2) RF_LAUNCH_ONE(true, false, 4);
-                else if (narrow) RF_LAUNCH_ONE(false, false, 2);
-                else RF_LAUNCH_ONE(false, false, 4);
+            if (one_sphere && pow2 && narrow) RF_LAUNCH_ONE(true, true, 2);
+            else if (one_sphere && pow2) RF_LAUNCH_ONE(true, true, 4);
+            else if (one_sphere && narrow) RF_LAUNCH_ONE(false, true, 2);
+            else if (one_sphere) RF_LAUNCH_ONE(false, true, 4);
+            else if (pow2 && narrow) RF_LAUNCH_ONE(true, false, 2);
+            else if (pow2) RF_LAUNCH_ONE(true, false, 4);
+            else if (narrow) RF_LAUNCH_ONE(false, false, 2);
+            else RF_LAUNCH_ONE(false, false, 4);
 #undef RF_LAUNCH_ONE
-            } else if (pow2) {
-                hipLaunchKernelGGL(rf::render_general_kernel<true>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
-                ctx->render_kernel = "render_general_kernel<true>";
-            } else {
-                hipLaunchKernelGGL(rf::render_general_kernel<false>, dim3(gx, ne), dim3(rf::kBlock), 0, ctx->stream, b);
-                ctx->render_kernel = "render_general_kernel<false>";
-            }
-            he = hipGetLastError();
         }
+        RF_HIP(hipGetLastError());
         ctx->general_redo_last = 0;
-        if (he == hipSuccess && one_shape) // (diagnostics: rf_general_redo_pixels)
-            he = hipMemcpyAsync(&ctx->general_redo_last, scratch + o_redo, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        if (listed) {
+            // how many pixels abstained, per launch; a launch with more of them than the list holds is rendered again, whole,
+            // by the literal kernel from the call's fresh states (every call starts from seed-0 states: render.py:115)
+            std::vector<unsigned> counts((size_t)n_chunks);
+            RF_HIP(hipMemcpyAsync(counts.data(), scratch + o_cnt, b_cnt, hipMemcpyDeviceToHost, ctx->stream));
+            RF_HIP(hipStreamSynchronize(ctx->stream));
+            unsigned long long redo = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                redo += counts[(size_t)c];
+                if (counts[(size_t)c] <= cap)
+                    continue;
+                const int e0 = c * chunk, ne = std::min(chunk, n - e0);
+                const uint64_t first = (uint64_t)e0 * hw64, count = (uint64_t)ne * hw64;
+                if (ctx->d_seed_cache && ctx->seed_cache_n == ctx->n_states) {
+                    RF_HIP(hipMemcpyAsync(ctx->d_states + first, ctx->d_seed_cache + first, count * sizeof(ulonglong2),
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+                } else {
+                    rc = seed_range(ctx, first, count, 0, first);
+                    if (rc != RF_OK)
+                        return rc;
+                }
+                launch_literal(chunk_args(e0, ne));
+                RF_HIP(hipGetLastError());
+            }
+            ctx->general_redo_last = (unsigned)std::min<unsigned long long>(redo, 0xFFFFFFFFull);
+        }
     }
-    if (he == hipSuccess)
-        he = hipStreamSynchronize(ctx->stream);
-    if (he != hipSuccess) {
-        set_err("rf_render_general: %s", hipGetErrorString(he));
-        return RF_ERR_HIP;
-    }
+    RF_HIP(hipStreamSynchronize(ctx->stream));
     if (host_out)
         return rf_get_frames(ctx, 0, n, host_out);
     return RF_OK;

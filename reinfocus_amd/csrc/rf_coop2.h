@@ -447,10 +447,10 @@ __device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLd
     static_assert(sizeof(lds.words4) >= (size_t)kSets * kBlock2 * 3, "stage does not fit");
     uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.words4);
 
-    if (!TWO && skip_env(a_in.rect, blockIdx.y)) // block-uniform, before any barrier
+    if (!TWO && skip_env(a_in.rect, (int)blockIdx.y)) // block-uniform, before any barrier
         return;
     const int passes = (TWO && a_in.env0 + (int)blockIdx.y < *a_in.count2) ? 2 : 1; // block-uniform
-    int e = blockIdx.y, block_x = blockIdx.x, tid = threadIdx.x;
+    int e = (int)blockIdx.y, block_x = (int)blockIdx.x, tid = threadIdx.x;
   for (int pass = 0; pass < passes; ++pass) {
     RenderArgs a_pass;
     if (TWO) {
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kBlock2, kSetsOcc) void render_kernel_coop2_strip(R
                   "render_tile_coop2<.., TWO> reads RenderArgs from offset 0 of the kernarg segment");
     __shared__ CoopLds2 lds;
     __shared__ float lds_colour[kColourLds][3][kBlock2];
-    if (skip_env(a_in.rect, blockIdx.y)) // (slots a launch for all n environments has to leave alone: never a real rectangle)
+    if (skip_env(a_in.rect, (int)blockIdx.y)) // (slots a launch for all n environments has to leave alone: never a real rectangle)
         return;
     if ((int)blockIdx.x < a_in.main_tiles) // block-uniform
         render_tile_coop2<false, LENS, MAIN_WX, 32, false, 1, true>(a_in, lds, lds_colour);

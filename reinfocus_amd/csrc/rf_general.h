@@ -24,10 +24,6 @@
 
 #include "rf_math.h"
 
-#ifndef RF_GTIME
-#define RF_GTIME 0 // (timing builds, wrong frames: see profiles/r05_ab.txt)
-#endif
-
 namespace rf {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -63,24 +59,6 @@ RF_HD bool sphere_hit(const float *sp, const float o[3], const float d[3], float
         if (disc < (reach * reach) * 0.99999904632568359375f /* 1 - 2^-20 */)
             return false;
     }
-#if RF_GTIME & 1
-    {
-        const float sq = __builtin_amdgcn_sqrtf(disc), ra = __builtin_amdgcn_rcpf(a);
-        float rootf = (-b - sq) * ra;
-        if (rootf < t_min || t_max < rootf) {
-            rootf = (-b + sq) * ra;
-            if (rootf < t_min || t_max < rootf)
-                return false;
-        }
-        const float inv_rf = __builtin_amdgcn_rcpf(radius);
-        for (int k = 0; k < 3; ++k) {
-            r.p[k] = add2(o[k], d[k] * rootf);
-            r.n[k] = (r.p[k] - centre[k]) * inv_rf;
-        }
-        r.t = rootf;
-        return true;
-    }
-#endif
     const double sqrtd = sqrt((double)disc);
     double root = (-(double)b - sqrtd) / (double)a;
     if (root < (double)t_min || (double)t_max < root) {
@@ -293,11 +271,7 @@ RF_HD bool world_hit(const float *params, const int32_t *types, int n_shapes, in
     // texture coordinates / checker colour of the closest hit only (the reference computes uv for
     // every candidate inside hit(); only the closest one's is ever read)
     const float *shape = params + (long)which * width;
-#if RF_GTIME & 16
-    rec.red = true;
-#else
     rec.red = types[which] == 0 ? sphere_red(rec.n, shape[4], shape[5]) : rectangle_red(shape, rec);
-#endif
     return true;
 }
 
@@ -341,15 +315,7 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
         HitRec rec;
         if (world_hit(params, types, n_shapes, width, o, d, 0.001f, 1000000.0f, rec)) {
             float q0, q1, q2;
-#if RF_GTIME & 8
-            {
-                uint32_t w6[6];
-                sphere_attempt(g, w6);
-                sphere_finish(w6, q0, q1, q2);
-            }
-#else
             sphere_sample(g, q0, q1, q2);
-#endif
             scatter_step(rec, q0, q1, q2, o, d, ar, ag, ab);
         } else {
             return sky_colour(d, ar, ag, ab);
@@ -371,6 +337,9 @@ struct GeneralCamera {
     // the leading `0 + a` of the two three-term sums
     double u64[3], v64[3];
     float origin0[3], lower_left0[3];
+    // the lens radius split for the float32 form of the lens offset (rf_math.h lens_offset<1>: rf_general_dense.h uses
+    // it where the host has proven it exact for this radius)
+    float lens_hi, lens_lo;
 };
 
 RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
@@ -385,6 +354,8 @@ RF_HD GeneralCamera general_camera(const double *cam /*[19]*/)
         c.origin0[k] = 0.0f + c.f[9 + k];
         c.lower_left0[k] = 0.0f + c.f[k];
     }
+    c.lens_hi = (float)c.lens_radius;
+    c.lens_lo = (float)(c.lens_radius - (double)c.lens_hi);
     return c;
 }
 
@@ -432,18 +403,6 @@ RF_HD void general_coords(Rng &g, int x, int y, const GeneralFrame &f, float &s,
 RF_HD void general_ray(const CamDyn &dyn, const CamStatic &cs, float p0, float p1, float s, float t, float o[3],
                        float d[3])
 {
-#if RF_GTIME & 2
-    {
-        const float r0 = p0 * (float)cs.lens_radius, r1 = p1 * (float)cs.lens_radius;
-        o[0] = add3(cs.ox, cs.ux * r0, cs.vx * r1);
-        o[1] = add3(cs.oy, cs.uy * r0, cs.vy * r1);
-        o[2] = add3(cs.oz, cs.uz * r0, cs.vz * r1);
-        d[0] = add3(dyn.llx, dyn.hx * s, dyn.vx * t) - o[0];
-        d[1] = add3(dyn.lly, dyn.hy * s, dyn.vy * t) - o[1];
-        d[2] = add3(dyn.llz, dyn.hz * s, dyn.vz * t) - o[2];
-        return;
-    }
-#endif
     const double rd0 = (double)p0 * cs.lens_radius, rd1 = (double)p1 * cs.lens_radius;
     o[0] = add3(cs.ox, (float)((double)cs.ux * rd0), (float)((double)cs.vx * rd1));
     o[1] = add3(cs.oy, (float)((double)cs.uy * rd0), (float)((double)cs.vy * rd1));
@@ -468,15 +427,7 @@ RF_HD void render_pixel_general(Rng &g, int x, int y, int h, int w, int spp, con
         float s, t;
         general_coords<POW2>(g, x, y, frame, s, t);
         float p0, p1;
-#if RF_GTIME & 4
-        {
-            uint32_t w4[4];
-            disc_attempt(g, w4);
-            disc_finish(w4, p0, p1);
-        }
-#else
         disc_sample(g, p0, p1);
-#endif
         float o[3], d[3];
         general_ray(dyn, cs, p0, p1, s, t, o, d);
         const Colour c = find_colour(params, types, n_shapes, width, o, d, g);

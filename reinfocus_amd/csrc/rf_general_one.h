@@ -32,17 +32,30 @@
 #pragma once
 
 #include "rf_coop2.h"
+#include "rf_general_dense.h"
 #include "rf_general_kernels.h"
 
 namespace rf {
 
+// arguments of the kernels that may leave pixels to the fix-up kernel (this file's, and rf_general_dense.h's)
 struct GeneralOneArgs {
     GeneralArgs g;
-    unsigned *redo_count; // [1], zeroed before the launch
-    unsigned *redo_list;  // [n * hw]: pixel indices (e * hw + p within the launch) for the fix-up kernel
+    unsigned *redo_count; // [1], zeroed before the launch: pixels that abstained (may exceed redo_cap)
+    unsigned *redo_list;  // [redo_cap]: pixel indices (e * hw + p within the launch) for the fix-up kernel
+    unsigned redo_cap;    // entries the list holds; a launch that abstains more often is rendered again by the literal
+                          // kernel from fresh states (rf_abi_general.hip)
+    const ShapeConst *shapes; // [n][NS] (render_general_dense_kernel)
     double w64, h64, rw64, rh64; // frame sizes and their reciprocals (pixel_coord_div); inv_w / inv_h for POW2
     float inv_w, inv_h;
 };
+
+// a pixel that abstains: counted always, listed while the list has room
+__device__ __forceinline__ void redo_append(const GeneralOneArgs &ra, unsigned pix)
+{
+    const unsigned slot = atomicAdd(ra.redo_count, 1u);
+    if (slot < ra.redo_cap)
+        ra.redo_list[slot] = pix;
+}
 
 // camera.get_ray (camera.py:307-350): general_ray of rf_general.h with the per-environment constants from the host
 // (GeneralCamera::u64 ...: loop invariants the kernel would otherwise keep in 18 vector registers)
@@ -118,7 +131,9 @@ render_general_one_kernel(GeneralOneArgs ra)
     uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.words4);
     __shared__ float lds_colour[kColourLds][3][kBlock2];
 
-    const int e = blockIdx.y;
+    // (one-dimensional grid, the environment fastest: see render_general_dense_kernel)
+    const int e = (int)(blockIdx.x % (unsigned)a.n);
+    const int block_in_env = (int)(blockIdx.x / (unsigned)a.n);
     const int tid = threadIdx.x;
     if (tid < 2)
         lds.cnt[tid] = 0;
@@ -126,7 +141,7 @@ render_general_one_kernel(GeneralOneArgs ra)
         lds.cnt2 = 0;
     __syncthreads();
     const int tiles_x = (a.w + tTileW - 1) / tTileW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int tile_y = block_in_env / tiles_x, tile_x = block_in_env - tile_y * tiles_x;
 
     // pixel geometry of a thread, re-derived inside the loop from an index the compiler cannot see through (rf_coop2.h)
     struct Geometry {
@@ -397,7 +412,7 @@ render_general_one_kernel(GeneralOneArgs ra)
         uint8_t r8 = 0, g8 = 0, b8 = 0;
         const bool keep = ge.live_of(j) && cr[j] == cr[j]; // (NaN: the pixel abstained)
         if (ge.live_of(j) && !keep) // abstain: state untouched, pixel listed for render_general_fixup_kernel
-            ra.redo_list[atomicAdd(ra.redo_count, 1u)] = (unsigned)pix_of(ge, j);
+            redo_append(ra, (unsigned)pix_of(ge, j));
         if (keep) {
             a.states[pix_of(ge, j)] = make_ulonglong2(rng_s0(g[j]), rng_s1(g[j]));
             r8 = (uint8_t)(cr[j] * a.scale);
@@ -438,10 +453,10 @@ render_general_one_kernel(GeneralOneArgs ra)
 // number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it
 // reads itself.
 template <bool POW2>
-__global__ __launch_bounds__(kBlock, kGeneralOcc) void render_general_fixup_kernel(GeneralOneArgs ra)
+__global__ __launch_bounds__(kBlock) void render_general_fixup_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
-    const unsigned total = *ra.redo_count;
+    const unsigned total = min(*ra.redo_count, ra.redo_cap); // (more than the list holds: the host renders the launch again)
     for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         const unsigned pix = ra.redo_list[i];
         const int e = (int)(pix / (unsigned)a.hw), p = (int)(pix - (unsigned)e * (unsigned)a.hw);
@@ -456,6 +471,109 @@ __global__ __launch_bounds__(kBlock, kGeneralOcc) void render_general_fixup_kern
         dst[0] = (uint8_t)(cr * a.scale);
         dst[1] = (uint8_t)(cg * a.scale);
         dst[2] = (uint8_t)(cb * a.scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// render_general_dense_kernel<POW2, NS>: device_render (render.py:31-85) for worlds of NS shapes per environment in
+// float32 / double-float arithmetic with pixel-level abstention (rf_general_dense.h).  One pixel per thread, lanes along
+// x, rejection and bounce loops inside the wave, frame bytes staged through LDS -- the literal kernel's organisation:
+// what changes is what a sample costs.  Scene constants come through the constant address space into scalar registers.
+constexpr int kDenseOcc = 7; // waves per SIMD the register allocator is held to
+// TILED: which pixels a block's 256 threads own -- a scheduling choice only (a pixel's RNG stream is its own): a 16 x 16
+// tile with waves of 8 x 8 pixels, or (frames that such tiles would pad too much: rf_abi_general.hip) 256 consecutive
+// pixels of the frame in row-major order.  Compact waves touch fewer of a shape's edge pixels, so fewer waves run the
+// hit-only code for a few lanes: 12 % fewer instructions on two-sphere scenes (lane utilisation 0.56 -> 0.64), and
+// row-major waves of a frame whose width is not a multiple of 64 straddle rows: +17 % at 300 px.  (16 x 4 pixel waves
+// are as fast, 32 x 2 ones 1 ... 6 % slower: profiles/r05_ab.txt section 3.)
+template <bool POW2, int NS, bool TILED>
+__global__ __launch_bounds__(kBlock, kDenseOcc) void render_general_dense_kernel(GeneralOneArgs ra)
+{
+    __shared__ uint32_t stage[kBlock * 3 / 4];
+    const GeneralArgs &a = ra.g;
+    // One-dimensional grid with the ENVIRONMENT as the fastest index (block b: environment b % n, tile b / n).  Blocks
+    // go to the eight XCDs round-robin by their index; with the tile index fastest, a scene whose expensive tiles sit at
+    // fixed columns (a sphere at the frame's edge: tile columns 0-5 and 10-15 of 16) gives some XCDs twice the work of
+    // others (measured: 0.24 instead of 0.34 VALU instructions per cycle per SIMD, profiles/r05_ab.txt section 3).
+    const int e = (int)(blockIdx.x % (unsigned)a.n);
+    const int block_in_env = (int)(blockIdx.x / (unsigned)a.n);
+    constexpr int tTileW = 16, tTileH = 16;
+    int x, y, p0 = 0, x0 = 0, y0 = 0;
+    bool live;
+    if (!TILED) {
+        p0 = block_in_env * kBlock;
+        const int p = p0 + threadIdx.x;
+        live = p < a.hw;
+        y = p / a.w;
+        x = p - y * a.w;
+    } else {
+        const int tiles_x = (a.w + tTileW - 1) / tTileW;
+        const int ty = block_in_env / tiles_x, tx = block_in_env - ty * tiles_x;
+        const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        x0 = tx * tTileW;
+        y0 = ty * tTileH;
+        x = x0 + (int)((wv & 1u) * 8u + (lane & 7u));
+        y = y0 + (int)((wv >> 1) * 8u + (lane >> 3));
+        live = x < a.w && y < a.h;
+    }
+    const size_t pix = (size_t)e * a.hw + (live ? (size_t)y * a.w + x : 0);
+    uint8_t r8 = 0, g8 = 0, b8 = 0;
+    if (live) {
+        const ulonglong2 st = a.states[pix];
+        Rng g = rng_load(st.x, st.y);
+        const_as<GeneralCamera> &cam = *as_const(a.cameras + e);
+        const_as<ShapeConst> *const sc = as_const(ra.shapes + (size_t)e * NS);
+        float cr, cg, cb;
+        const bool keep = render_pixel_dense<POW2, NS>(g, x, y, a.spp, cam, cam.lens_hi, cam.lens_lo, sc, ra.inv_w, ra.inv_h,
+                                                       ra.w64, ra.h64, ra.rw64, ra.rh64, cr, cg, cb);
+        if (keep) {
+            a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
+            r8 = (uint8_t)(cr * a.scale);
+            g8 = (uint8_t)(cg * a.scale);
+            b8 = (uint8_t)(cb * a.scale);
+        } else { // abstain: state untouched, pixel listed for render_general_fixup_kernel (its bytes below are placeholders)
+            redo_append(ra, (unsigned)pix);
+        }
+    }
+    uint8_t *sb = reinterpret_cast<uint8_t *>(stage);
+    if (!TILED) {
+        // a full block whose first byte is dword-aligned goes through LDS; anything else stores bytes (render_general_kernel)
+        const size_t first_byte = ((size_t)e * a.hw + p0) * 3;
+        const bool staged = p0 + kBlock <= a.hw && (reinterpret_cast<uintptr_t>(a.frames + first_byte) & 3) == 0; // block-uniform
+        if (staged) {
+            sb[threadIdx.x * 3 + 0] = r8;
+            sb[threadIdx.x * 3 + 1] = g8;
+            sb[threadIdx.x * 3 + 2] = b8;
+            __syncthreads();
+            if (threadIdx.x < kBlock * 3 / 4)
+                reinterpret_cast<uint32_t *>(a.frames + first_byte)[threadIdx.x] = stage[threadIdx.x];
+            return;
+        }
+    } else {
+        // a whole tile inside a frame whose rows are dwords (w % 4 == 0) and whose base is dword-aligned: the tile's rows
+        // (tTileW * 3 bytes each) go through LDS and leave as dword stores; anything else stores bytes
+        const bool staged = x0 + tTileW <= a.w && y0 + tTileH <= a.h && (a.w & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(a.frames + (size_t)e * a.hw * 3) & 3) == 0; // block-uniform
+        if (staged) {
+            const int slot = (y - y0) * tTileW + (x - x0);
+            sb[slot * 3 + 0] = r8;
+            sb[slot * 3 + 1] = g8;
+            sb[slot * 3 + 2] = b8;
+            __syncthreads();
+            constexpr int kRowDw = tTileW * 3 / 4;
+            if (threadIdx.x < tTileH * kRowDw) {
+                const int r = threadIdx.x / kRowDw, dw = threadIdx.x - r * kRowDw;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(a.frames + (((size_t)e * a.h + y0 + r) * a.w + x0) * 3);
+                dst[dw] = stage[r * kRowDw + dw];
+            }
+            return;
+        }
+    }
+    if (live) {
+        uint8_t *dst = a.frames + pix * 3;
+        dst[0] = r8;
+        dst[1] = g8;
+        dst[2] = b8;
     }
 }
 

@@ -160,6 +160,10 @@ struct Timed {
 // call that may reallocate a buffer or change the scene / configuration drops it.
 void drop_env_graph(rf_ctx *ctx);
 
+// states [first, first + count) of the context's array := the states of `seed` at indices first_state_index ...
+// (rf_seed is this for the whole array)
+int seed_range(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t seed, uint64_t first_state_index);
+
 // Splits the lens radius for rf_math.h lens_offset and decides whether the float32 form is exact for it
 void lens_split(rf::CamStatic &cs);
 

@@ -7,12 +7,16 @@
 #include <string.h>
 #include <stdint.h>
 
+#define RF_HOSTSIM 1 // (rf_general_dense.h: its 1-ulp approximations can be nudged from here)
 #include "../../reinfocus_amd/csrc/rf_math.h"
 #include "../../reinfocus_amd/csrc/rf_jump.h"
 #include "../../reinfocus_amd/csrc/rf_general.h"
+#include "../../reinfocus_amd/csrc/rf_general_dense.h"
 #include "../gpucheck/probe_general.h"
 
 using namespace rf;
+
+thread_local unsigned rf::g_dense_perturb = 0;
 
 static CheckerTable host_checker_table()
 {
@@ -395,6 +399,111 @@ long hs_check_sphere_hit(const float *spheres, const float *origins, const float
     *hits = n_hit;
     *shortcuts = n_short;
     return bad;
+}
+
+// rf_general_dense.h sphere_hit_dense (float32 / double-float with abstention) next to the literal float64 form on the
+// same rays: wherever it does not abstain, the answer and every bit of a hit's record must be the literal one's.
+// perturb != 0: the 1-ulp approximations (sqrt, reciprocals) are nudged by -1 / 0 / +1 ulp at random.
+// counts = {hits, misses decided, abstentions}; max_err = the largest relative error of the double-float root against
+// long double (x86: 64 significant bits) over the rays whose root was evaluated, in units of the bound it is used with
+// (tol / 4: must stay below 1).
+long hs_check_sphere_hit_dense(const float *spheres, const float *origins, const float *dirs, float t_min, float t_max, long n,
+                               unsigned perturb, long *counts, double *max_err)
+{
+    long bad = 0, n_hit = 0, n_miss = 0, n_doubt = 0;
+    double worst = 0.0;
+#pragma omp parallel for reduction(+ : bad, n_hit, n_miss, n_doubt) reduction(max : worst)
+    for (long i = 0; i < n; ++i) {
+        const float *sp = spheres + 4 * i, *o = origins + 3 * i, *d = dirs + 3 * i;
+        float want[7] = {0, 0, 0, 0, 0, 0, 0};
+        const bool hit = sphere_hit_literal(sp, o, d, t_min, t_max, want);
+        rf::g_dense_perturb = perturb ? (perturb + (unsigned)i * 2654435761u) | 1u : 0u;
+        rf::HitRec r;
+        const float centre[3] = {sp[0], sp[1], sp[2]};
+        const rf::ShapeConst sc = rf::shape_const(sp, 4, 0);
+        const int got = rf::sphere_hit_dense(centre, sc.k[0], sc.k[1], o, d, rf::dot3(d, d), t_min, t_max, r);
+        if (got == rf::kDoubt) {
+            ++n_doubt;
+        } else {
+            const float have[7] = {r.p[0], r.p[1], r.p[2], r.n[0], r.n[1], r.n[2], r.t};
+            if ((got == rf::kHit) != hit || (hit && memcmp(want, have, sizeof(want)) != 0))
+                ++bad;
+            n_hit += hit ? 1 : 0;
+            n_miss += hit ? 0 : 1;
+        }
+        // the double-float root itself against long double, wherever it is evaluated
+        const float oc[3] = {o[0] - sp[0], o[1] - sp[1], o[2] - sp[2]};
+        const float a = rf::dot3(d, d), b = rf::dot3(oc, d), c = rf::dot3(oc, oc) - sp[3] * sp[3];
+        const float disc = b * b - a * c;
+        if (disc > 0 && rf::magnitude_within(a, -40, 40) && rf::magnitude_within(disc, -60, 60) &&
+            (b == 0.0f || rf::magnitude_within(b, -60, 40))) {
+            for (int sgn = 1; sgn >= -1; sgn -= 2) {
+                float qh, ql, tol;
+                if (!rf::sphere_root_df(a, b, disc, (float)sgn, qh, ql, tol))
+                    continue;
+                const long double exact = (-(long double)b - (long double)sgn * sqrtl((long double)disc)) / (long double)a;
+                const long double err = fabsl(((long double)qh + (long double)ql) - exact) / fabsl(exact);
+                const double units = (double)(err / ((long double)tol * 0.25L)); // in units of the bound (tol = 4x bound)
+                worst = units > worst ? units : worst;
+            }
+        }
+    }
+    rf::g_dense_perturb = 0;
+    counts[0] = n_hit;
+    counts[1] = n_miss;
+    counts[2] = n_doubt;
+    *max_err = worst;
+    return bad;
+}
+
+// rf_general_dense.h render_pixel_dense on the host: frames / states of the pixels that do not abstain, and which did
+// (abstained[pix] = 1: frame bytes and state untouched).  NS = most in {1, 2}; cameras must be simple (returns -1 if not).
+int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const double *cameras, const float *params,
+                            const int32_t *types, const int32_t *sizes, int most, int width, uint64_t *states,
+                            uint8_t *abstained, unsigned perturb)
+{
+    const float scale = (float)(255.0 / (double)spp);
+    const bool pow2 = h > 0 && w > 0 && (h & (h - 1)) == 0 && (w & (w - 1)) == 0;
+    if (most < 1 || most > 2 || h > 4096 || w > 4096)
+        return -1;
+    for (int e = 0; e < n; ++e) {
+        if (sizes[e] != most)
+            return -1;
+        const GeneralCamera cam = general_camera(cameras + (long)e * 19);
+        CamStatic cs{0, 0, 0, 0, 0, 0, 0, 0, 0, cam.lens_radius, cam.lens_hi, cam.lens_lo, 0};
+        if (!camera_axes_simple(cam))
+            return -1;
+        // (the exhaustive check of the radius: rf_abi_ctx.hip lens_split; here on the fly for the coordinates that occur)
+        ShapeConst sc[2];
+        for (int i = 0; i < most; ++i)
+            sc[i] = shape_const(params + ((long)e * most + i) * width, width, types[(long)e * most + i]);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const long pix = ((long)e * h + y) * w + x;
+                Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
+                float cr, cg, cb;
+                rf::g_dense_perturb = perturb ? (perturb + (unsigned)pix * 2654435761u) | 1u : 0u;
+                bool keep;
+#define HS_DENSE(P, N) keep = render_pixel_dense<P, N>(g, x, y, spp, cam, cam.lens_hi, cam.lens_lo, sc, 1.0f / (float)w, \
+                                                       1.0f / (float)h, (double)w, (double)h, 1.0 / (double)w, 1.0 / (double)h, cr, cg, cb)
+                if (pow2 && most == 1) HS_DENSE(true, 1);
+                else if (pow2) HS_DENSE(true, 2);
+                else if (most == 1) HS_DENSE(false, 1);
+                else HS_DENSE(false, 2);
+#undef HS_DENSE
+                abstained[pix] = keep ? 0 : 1;
+                if (!keep)
+                    continue;
+                states[2 * pix] = rng_s0(g);
+                states[2 * pix + 1] = rng_s1(g);
+                frames[pix * 3 + 0] = (uint8_t)(cr * scale);
+                frames[pix * 3 + 1] = (uint8_t)(cg * scale);
+                frames[pix * 3 + 2] = (uint8_t)(cb * scale);
+            }
+        (void)cs;
+    }
+    rf::g_dense_perturb = 0;
+    return 0;
 }
 
 int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)

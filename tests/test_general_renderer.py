@@ -327,3 +327,132 @@ def test_sphere_miss_shortcut_equals_the_float64_roots(oracle):
         got = hs.hs_check_sphere_hit(ptr(spheres[i:i + 1]), ptr(origin[i:i + 1]), ptr(direction[i:i + 1]), ctypes.c_float(0.001),
                                      ctypes.c_float(1000000.0), ctypes.c_long(1), ctypes.byref(hits), ctypes.byref(shortcuts))
         assert got == 0 and bool(hits.value) == bool(want_hit)
+
+
+# --- the float32 kernel with abstentions (rf_general_dense.h) ---------------------------------------------------------
+
+
+def _few_shape_worlds(rng, n, most, kinds="both"):
+    """n environments of exactly `most` shapes (spheres and / or rectangles, overlapping in depth and on the screen, some
+    spheres large and near the camera) seen by cameras whose axes are the canonical ones -- look_at straight ahead of an
+    off-centre look_from -- through the reference's default aperture: the worlds render_general_dense_kernel takes."""
+    from reinfocus_amd.graphics import camera, shape, world
+
+    cams, envs = [], []
+    for _ in range(n):
+        origin = (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2))
+        cams.append(camera.make_gpu_camera(focus_distance=rng.uniform(4, 12), vfov=rng.uniform(20, 55),
+                                           aspect_ratio=rng.uniform(0.7, 1.8), look_from=origin,
+                                           look_at=(origin[0], origin[1], origin[2] - 10.0)))
+        shapes = []
+        for _ in range(most):
+            z = -rng.uniform(3, 12)
+            x, y = rng.uniform(-2, 2), rng.uniform(-1.5, 1.5)
+            tex = (int(rng.integers(1, 20)), int(rng.integers(1, 20)))
+            sphere = rng.random() < 0.5 if kinds == "both" else kinds == "sphere"
+            if sphere:
+                radius = rng.uniform(0.3, 2.5) if rng.uniform() < 0.9 else rng.uniform(1.0, 1.2) * abs(z)  # (around the camera)
+                shapes.append(shape.sphere(shape.v3f(x, y, z), radius, shape.v2f(*tex)))
+            else:
+                s = rng.uniform(0.3, 2.5)
+                shapes.append(shape.rectangle(shape.v2f(x - s, x + s), shape.v2f(y - s, y + s), z, shape.v2f(*tex)))
+        envs.append(shapes)
+    params, types, sizes = world.Worlds(*envs).device_data()
+    if params.shape[2] < 7:
+        params = np.pad(params, ((0, 0), (0, 0), (0, 7 - params.shape[2])))
+    return (np.ascontiguousarray(camera.Cameras(*cams).device_data(), dtype=np.float64),
+            (np.ascontiguousarray(params, dtype=np.float32), np.ascontiguousarray(types, dtype=np.int32),
+             np.ascontiguousarray(sizes, dtype=np.int32)))
+
+
+def _factory_worlds(rng, n, label):
+    """The reference's own two-shape factories (shape_factory.py:69-196) at random distances, default cameras."""
+    from reinfocus_amd.graphics import camera, shape_factory as sf, world
+
+    make = {"two_sphere": lambda d: sf.two_sphere(sf.ShapeParameters(d + 10), sf.ShapeParameters(d)),
+            "two_rect": lambda d: sf.two_rect(sf.ShapeParameters(d + 10), sf.ShapeParameters(d)),
+            "mixed": lambda d: sf.mixed(sf.ShapeParameters(d), sf.ShapeParameters(d + 5))}[label]
+    params, types, sizes = world.Worlds(*[make(float(d)) for d in rng.uniform(5, 10, n)]).device_data()
+    if params.shape[2] < 7:
+        params = np.pad(params, ((0, 0), (0, 0), (0, 7 - params.shape[2])))
+    cams = camera.Cameras(*[camera.make_gpu_camera(focus_distance=float(f)) for f in rng.uniform(5, 10, n)])
+    return (np.ascontiguousarray(cams.device_data(), dtype=np.float64),
+            (np.ascontiguousarray(params, dtype=np.float32), np.ascontiguousarray(types, dtype=np.int32),
+             np.ascontiguousarray(sizes, dtype=np.int32)))
+
+
+def test_double_float_sphere_roots_decide_like_the_float64_ones():
+    """rf_general_dense.h sphere_hit_dense -- float32 discriminant, the root in double-float, abstention near every
+    comparison bound and every float32 rounding boundary -- against the reference's float64 expressions
+    (sphere.py:40-103) on rays of every kind (leaving the surface, starting next to it, aimed from afar; tiny and huge
+    directions): wherever it does not abstain, the hit flag and every bit of the record are the literal ones'.  The
+    device evaluates sqrt and the reciprocals to 1 ulp; here they are correctly rounded and nudged by -1 / 0 / +1 ulp, so
+    nothing may depend on more than 1.5 ulp.  The measured error of the double-float root stays below the bound its
+    abstention margins are derived from (they are 4x the bound), and rays aimed at a sphere from afar -- the rays of a
+    render -- abstain less than once in 10^4."""
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    hs.hs_check_sphere_hit_dense.restype = ctypes.c_long
+    rng = np.random.default_rng(12)
+    n = 3_000_000
+    centre = rng.uniform(-5, 5, (n, 3))
+    radius = rng.uniform(0.1, 8, n)
+    unit = rng.normal(size=(n, 3))
+    unit /= np.linalg.norm(unit, axis=1, keepdims=True)
+    kind = rng.integers(0, 4, n)
+    offset = np.select([kind == 0, kind == 1, kind == 2], [1.0, 1.0 + rng.choice([-1, 1], n) * 10.0 ** rng.uniform(-7, -2, n),
+                                                            1.0 + 10.0 ** rng.uniform(-4, 0, n)], rng.uniform(1.05, 6, n))
+    origin = centre + unit * (radius * offset)[:, None]
+    wobble = rng.normal(size=(n, 3))
+    wobble *= (rng.uniform(0, 1.0, n) ** (1 / 3) / np.linalg.norm(wobble, axis=1))[:, None]
+    aimed = (centre + rng.normal(size=(n, 3)) * radius[:, None] * rng.uniform(0, 1.5, n)[:, None]) - origin
+    direction = np.where((kind == 3)[:, None], aimed, unit + wobble)
+    direction[: n // 100] *= 1e-4
+    direction[n // 100: n // 50] *= 1e4
+    spheres = np.ascontiguousarray(np.column_stack([centre, radius]).astype(np.float32))
+    origin = np.ascontiguousarray(origin.astype(np.float32))
+    direction = np.ascontiguousarray(direction.astype(np.float32))
+    counts, err = (ctypes.c_long * 3)(), ctypes.c_double(0)
+    for perturb in (0, 4711):
+        for t_min, t_max in ((0.001, 1000000.0), (0.001, 3.0)):
+            bad = hs.hs_check_sphere_hit_dense(ptr(spheres), ptr(origin), ptr(direction), ctypes.c_float(t_min),
+                                               ctypes.c_float(t_max), ctypes.c_long(n), ctypes.c_uint(perturb), counts,
+                                               ctypes.byref(err))
+            assert bad == 0, (perturb, t_min, t_max, bad)
+            assert counts[0] > n // 10 and counts[1] > n // 4, list(counts)  # hits and decided misses are exercised
+            assert err.value < 0.8, err.value  # (fraction of the error bound; the margins are 4x the bound)
+    aimed_rays = kind == 3
+    sp, o, d = (np.ascontiguousarray(a[aimed_rays]) for a in (spheres, origin, direction))
+    bad = hs.hs_check_sphere_hit_dense(ptr(sp), ptr(o), ptr(d), ctypes.c_float(0.001), ctypes.c_float(1e6), ctypes.c_long(len(sp)),
+                                       ctypes.c_uint(1), counts, ctypes.byref(err))
+    assert bad == 0 and counts[2] < len(sp) // 2000, list(counts)
+
+
+@pytest.mark.parametrize("label,n,h,w,spp", [("two_sphere", 3, 64, 64, 16), ("mixed", 3, 64, 64, 16), ("two_rect", 2, 48, 80, 8),
+                                             ("mixed", 2, 50, 70, 60), ("random2", 6, 40, 56, 8), ("random1", 6, 32, 32, 8),
+                                             ("random2", 3, 64, 32, 20)])
+def test_dense_kernel_arithmetic_equals_oracle_wherever_it_does_not_abstain(oracle, label, n, h, w, spp):
+    """rf_general_dense.h render_pixel_dense compiled for the host on the reference's two-shape factories and on random
+    worlds of one and two shapes: every pixel that does not abstain has the oracle's bytes and final RNG state (also
+    with the 1-ulp approximations nudged), the pixels that abstain are left untouched, and they are few."""
+    hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
+    p = ctypes.c_void_p
+    hs.hs_render_general_dense.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p, p, ctypes.c_uint]
+    rng = np.random.default_rng(n * 100 + h)
+    cameras, (params, types, sizes) = (_few_shape_worlds(rng, n, int(label[-1])) if label.startswith("random")
+                                       else _factory_worlds(rng, n, label))
+    st0 = oracle.seed_states(n * h * w, 0)
+    st = st0.copy()
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=8)
+    for perturb in (0, 99):
+        got, s2, gave_up = np.zeros_like(want), st0.copy(), np.zeros(n * h * w, dtype=np.uint8)
+        rc = hs.hs_render_general_dense(got.ctypes.data, n, h, w, spp, cameras.ctypes.data, params.ctypes.data, types.ctypes.data,
+                                        sizes.ctypes.data, params.shape[1], params.shape[2], s2.ctypes.data, gave_up.ctypes.data,
+                                        perturb)
+        assert rc == 0
+        keep = gave_up.reshape(n, h, w) == 0
+        assert np.array_equal(got[keep], want[keep])
+        assert np.array_equal(s2.reshape(n, h, w, 2)[keep], st.reshape(n, h, w, 2)[keep])
+        assert np.array_equal(s2.reshape(n, h, w, 2)[~keep], st0.reshape(n, h, w, 2)[~keep])
+        assert gave_up.mean() < 0.0005 * spp + 0.002, gave_up.mean()  # (about 1e-4 per sample; spheres around the camera more)
+    assert len(np.unique(want)) > 20

@@ -8,7 +8,7 @@ import pytest
 
 from tests import helpers
 
-from tests.test_general_renderer import _random_scene
+from tests.test_general_renderer import _factory_worlds, _few_shape_worlds, _random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -277,6 +277,165 @@ def test_every_abstention_of_the_one_shape_kernel_is_repaired(oracle, tmp_path, 
         assert int(got["redo"]) > n * h * w // 20, "the test build should abstain on many pixels"
         assert np.array_equal(got["frames"], want)
         assert np.array_equal(got["states"], st)
+
+
+# --- worlds of one or two shapes per environment: the float32 kernel with abstentions (rf_general_dense.h) -------------
+
+
+def _general_in_child(tmp_path, scene, h, w, spp, env):
+    """rf_render_general in a child process (another library, or switches the library reads when a context is created)"""
+    import subprocess
+    import sys
+
+    cameras, (params, types, sizes) = scene
+    np.savez(tmp_path / "scene.npz", cameras=cameras, params=params, types=types, sizes=sizes)
+    out = tmp_path / "out.npz"
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reinfocus_amd import _native\n"
+        "d = np.load(%r)\n"
+        "c = _native.Context(0)\n"
+        "f = c.render_general(d['cameras'], d['params'], d['types'], d['sizes'], %d, %d, %d)\n"
+        "np.savez(%r, frames=f, states=c.get_states(0, %d), redo=c.general_redo_pixels(), kernel=c.render_kernel_name())\n"
+        "c.close()\n"
+    ) % (helpers.ROOT, str(tmp_path / "scene.npz"), h, w, spp, str(out), len(sizes) * h * w)
+    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, **env))
+    got = np.load(out)
+    return got["frames"], got["states"], int(got["redo"]), str(got["kernel"])
+
+
+@pytest.mark.parametrize("label,n,h,w,spp", [("two_sphere", 4, 64, 64, 16), ("mixed", 4, 128, 128, 8), ("two_rect", 3, 48, 80, 8),
+                                             ("mixed", 2, 300, 300, 12), ("random2", 8, 40, 56, 8), ("random1", 6, 32, 32, 8),
+                                             ("random2", 5, 33, 35, 6), ("random2", 3, 256, 256, 5), ("random1", 3, 100, 164, 7),
+                                             ("two_sphere", 2, 60, 100, 100), ("random2", 4, 64, 8, 5), ("random2", 6, 7, 90, 4),
+                                             ("mixed", 3, 12, 256, 6)])
+def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle, monkeypatch, label, n, h, w, spp):
+    """Worlds of one or two shapes in every environment, seen by cameras with canonical axes through an aperture whose
+    float32 lens offset is exact, are rendered by render_general_dense_kernel (rf_general_dense.h: no float64, the
+    sphere's roots in double-float, pixel-level abstention) + the fix-up kernel: frames and final RNG states
+    bit-identical to the oracle's -- power-of-two and other frames, widths that are not multiples of four (byte stores),
+    partial tiles, overlapping shapes, spheres around the camera, 100 samples; frames narrower or lower than a 16 x 16 tile,
+    which keep the row-major pixel order (full 256-pixel runs through the staged store, partial ones by bytes) -- and the
+    literal kernel, asked for with REINFOCUS_GENERAL_DENSE=0, gives the same."""
+    from reinfocus_amd import _native
+
+    rng = np.random.default_rng(n * 100 + h)
+    cameras, (params, types, sizes) = (_few_shape_worlds(rng, n, int(label[-1])) if label.startswith("random")
+                                       else _factory_worlds(rng, n, label))
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+    monkeypatch.setenv("REINFOCUS_GENERAL_ONE", "0")  # (one-shape worlds: not the cooperative kernel of rf_general_one.h)
+    dense = _native.Context(0)
+    monkeypatch.setenv("REINFOCUS_GENERAL_DENSE", "0")
+    literal = _native.Context(0)
+    try:
+        for c, kernel in ((dense, "render_general_dense_kernel"), (literal, "render_general_kernel")):
+            got = c.render_general(cameras, params, types, sizes, h, w, spp)
+            assert c.render_kernel_name().startswith(kernel), c.render_kernel_name()
+            if c is dense:  # 16 x 16 tiles unless they pad the frame more than 15 % beyond what 256-pixel runs do
+                tiled = -(-w // 16) * -(-h // 16) * 100 <= -(-h * w // 256) * 115
+                assert c.render_kernel_name().endswith(", true>" if tiled else ", false>"), c.render_kernel_name()
+            differing = np.any(got != want, axis=-1).sum()
+            assert differing == 0, f"{kernel}: {differing} of {n * h * w} pixels differ"
+            assert np.array_equal(c.get_states(0, n * h * w), st), kernel
+        assert dense.general_redo_pixels() < n * h * w * (0.0005 * spp + 0.002)
+    finally:
+        dense.close()
+        literal.close()
+
+
+def test_worlds_the_dense_kernel_does_not_take(ctx, oracle):
+    """Cameras that look from the side (axes with components other than 0 and +-1), apertures whose float32 lens offset
+    is not exact, worlds of three shapes or of different counts: the literal kernel, as before."""
+    from reinfocus_amd.graphics import camera, shape_factory as sf, world
+
+    two = sf.two_sphere(sf.ShapeParameters(12.0), sf.ShapeParameters(6.0))
+    side = camera.Cameras(camera.make_gpu_camera(look_from=(1.0, 0.5, 0.0)), camera.make_gpu_camera())
+    p, t, s = world.Worlds(two, two).device_data()
+    ctx.render_general(side.device_data(), p, t, s, 32, 32, 2)
+    assert ctx.render_kernel_name().startswith("render_general_kernel")
+    straight = camera.Cameras(camera.make_gpu_camera(), camera.make_gpu_camera())
+    ctx.render_general(straight.device_data(), p, t, s, 32, 32, 2)
+    assert ctx.render_kernel_name().startswith("render_general_dense_kernel")
+    p3, t3, s3 = world.Worlds(two + sf.one_rect(), two + sf.one_rect()).device_data()
+    ctx.render_general(straight.device_data(), p3, t3, s3, 32, 32, 2)
+    assert ctx.render_kernel_name().startswith("render_general_kernel")
+    pr, tr, sr = world.Worlds(two, sf.one_sphere()).device_data()
+    ctx.render_general(straight.device_data(), pr, tr, sr, 32, 32, 2)
+    assert ctx.render_kernel_name().startswith("render_general_kernel")
+    # apertures for which rf_abi_ctx.hip lens_split finds disc coordinates whose float32 offset differs from the float64
+    # one (the radii of tests/test_gpu_parity.py::test_lens_radius_forms), and two for which it finds none
+    for aperture, dense in ((2 * 0.6243510725689605, False), (2 * 0.46456785704581477, False), (0.14, True), (0.125, True)):
+        cams = camera.Cameras(camera.make_gpu_camera(aperture=aperture), camera.make_gpu_camera(aperture=aperture))
+        st = oracle.seed_states(2 * 24 * 24, 0)
+        want = oracle.render_general(cams.device_data(), p, t, s, 24, 24, 3, st, n_threads=4)
+        assert np.array_equal(ctx.render_general(cams.device_data(), p, t, s, 24, 24, 3), want), aperture
+        assert ctx.render_kernel_name().startswith("render_general_dense_kernel" if dense else "render_general_kernel"), aperture
+
+
+def test_a_fix_up_list_that_overflows_is_rendered_again_by_the_literal_kernel(oracle, tmp_path):
+    """The fix-up list holds a sixteenth of a launch's pixels (at least 65 536); a launch in which more pixels abstain is
+    rendered again, whole, by the literal kernel from the call's fresh seed-0 states.  REINFOCUS_GENERAL_REDO_CAP=1
+    makes that happen at test size (a two-sphere scene at 16 samples has a few abstentions per thousand pixels), for
+    the dense kernel and for the cooperative one-shape kernel; the call's count is the sum over its launches."""
+    rng = np.random.default_rng(3)
+    scene = _factory_worlds(rng, 4, "two_sphere")
+    n, h, w, spp = 4, 64, 64, 16
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(scene[0], *scene[1], h, w, spp, st, n_threads=16)
+    frames, states, redo, kernel = _general_in_child(tmp_path, scene, h, w, spp, {"REINFOCUS_GENERAL_REDO_CAP": "1"})
+    assert kernel.startswith("render_general_dense_kernel") and redo >= 2, (kernel, redo)
+    assert np.array_equal(frames, want) and np.array_equal(states, st)
+    scene = _random_one_shape_worlds(np.random.default_rng(4), 4, "sphere")
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(scene[0], *scene[1], h, w, spp, st, n_threads=16)
+    frames, states, redo, kernel = _general_in_child(tmp_path, scene, h, w, spp, {"REINFOCUS_GENERAL_REDO_CAP": "1"})
+    assert kernel.startswith("render_general_one_kernel") and redo >= 2, (kernel, redo)
+    assert np.array_equal(frames, want) and np.array_equal(states, st)
+
+
+@pytest.mark.parametrize("label", ["two_sphere", "mixed", "random2"])
+def test_every_abstention_of_the_dense_kernel_is_repaired(oracle, tmp_path, label):
+    """The dense kernel abstains where float32 cannot be proven to give the reference's bits -- a root next to a
+    comparison bound or a rounding boundary, a checker colour next to an edge -- about once in 10^3 pixels, and what it
+    would have computed there is almost always right anyway: an abstention that got lost would go unnoticed.  The
+    RF_TEST_DOUBT build (tests/gpucheck) abstains at a fifth of its decisions and computes whatever abstains WRONG on
+    purpose (inverted checker sign, displaced hit point): most pixels are listed -- with the list's default capacity,
+    and with one that overflows -- and frames and RNG states must still be the oracle's."""
+    so = helpers.built("tests/gpucheck", "libreinfocus_doubt.so")
+    rng = np.random.default_rng(22)
+    for n, h, w, spp in ((4, 64, 64, 6), (3, 40, 52, 5)):
+        scene = _few_shape_worlds(rng, n, 2) if label == "random2" else _factory_worlds(rng, n, label)
+        st = oracle.seed_states(n * h * w, 0)
+        want = oracle.render_general(scene[0], *scene[1], h, w, spp, st, n_threads=16)
+        for env in ({}, {"REINFOCUS_GENERAL_REDO_CAP": "100"}):
+            frames, states, redo, kernel = _general_in_child(tmp_path, scene, h, w, spp, dict(env, REINFOCUS_HIP_LIB=so))
+            assert kernel.startswith("render_general_dense_kernel"), kernel
+            assert redo > n * h * w // 20, "the test build should abstain on many pixels"
+            assert np.array_equal(frames, want), env
+            assert np.array_equal(states, st), env
+
+
+def test_dense_kernel_beyond_one_launch(ctx, oracle):
+    """65 540 environments of two shapes each in two launches (65 535 environments per launch), 5 x 5 pixel frames (75
+    bytes: the second launch's frames start at an address that is not dword-aligned) and 4 x 8 (the staged store path),
+    each launch with its own fix-up count."""
+    for h, w in ((5, 5), (4, 8)):
+        n, spp = 65_540, 2
+        cameras8, (params8, types8, sizes8) = _few_shape_worlds(np.random.default_rng(10), 8, 2)
+        reps = -(-n // 8)
+        cameras = np.ascontiguousarray(np.tile(cameras8, (reps, 1))[:n])
+        params = np.ascontiguousarray(np.tile(params8, (reps, 1, 1))[:n])
+        types = np.ascontiguousarray(np.tile(types8, (reps, 1))[:n])
+        sizes = np.ascontiguousarray(np.tile(sizes8, reps)[:n])
+        st = oracle.seed_states(n * h * w, 0)
+        want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
+        got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
+        assert ctx.render_kernel_name().startswith("render_general_dense_kernel")
+        assert np.array_equal(got[:65_535], want[:65_535]), "first launch"
+        assert np.array_equal(got[65_535:], want[65_535:]), "second launch"
+        assert np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
 def test_device_math_library_reaches_the_same_float32():

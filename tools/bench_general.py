@@ -51,12 +51,13 @@ def main():
                 _native._ptr(sizes), params.shape[1], params.shape[2], None)
         _native._check(lib.rf_render_general(*args))
         ctx.synchronize()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+        times = []
+        for _ in range(5):  # (the median: now and then a call on a shared box takes twice as long)
+            t0 = time.perf_counter()
             _native._check(lib.rf_render_general(*args))
-        ctx.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+            ctx.synchronize()
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
         print(f"{label}: {n} envs x {frame}^2 x {spp} spp: {dt * 1e3:.2f} ms per render "
               f"(incl. re-seeding), {n * frame * frame * spp / dt / 1e9:.2f} G samples/s, "
               f"{ctx.general_redo_pixels() / (n * frame * frame):.4%} of the pixels fixed up, "
