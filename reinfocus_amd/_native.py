@@ -322,7 +322,8 @@ class Context:
         return out
 
     # --- general renderer ------------------------------------------------------------------
-    def render_general(self, cameras, params, types, sizes, h, w, spp):
+    def render_general(self, cameras, params, types, sizes, h, w, spp, to_host=True):
+        """rf_render_general; to_host=False leaves the frames on the device (rf_get_frames fetches them)."""
         cameras = np.ascontiguousarray(cameras, dtype=np.float64)
         params = np.ascontiguousarray(params, dtype=np.float32)
         types = np.ascontiguousarray(types, dtype=np.int32)
@@ -332,9 +333,9 @@ class Context:
         if width < 7:  # the kernel reads up to 7 parameters per shape
             params = np.ascontiguousarray(np.pad(params, ((0, 0), (0, 0), (0, 7 - width))))
             width = 7
-        out = np.empty((n, h, w, 3), dtype=np.uint8)
+        out = np.empty((n, h, w, 3), dtype=np.uint8) if to_host else None
         _check(self._lib.rf_render_general(self._h, n, h, w, spp, _ptr(cameras), _ptr(params), _ptr(types),
-                                           _ptr(sizes), most, width, _ptr(out)))
+                                           _ptr(sizes), most, width, _ptr(out) if to_host else None))
         return out
 
     # --- device-resident env step ----------------------------------------------------------

@@ -132,7 +132,10 @@ constexpr int kTwoRoundsMin = 64;   // sphere entries above which the packing ro
 constexpr int kRound1Sphere = 2;    // attempts per entry in the packing round
 constexpr int kAdaptOn = 32, kAdaptOff = -32; // hysteresis of the per-block switch between one and two in-wave attempts
 constexpr int kColourLds = 2;       // pixel sets whose colour sums live in LDS
-constexpr int kTailPrio = 1;        // s_setprio of the waves inside coop_workers (0 / 1 / 2 / 3: 151.5 / 155.5 / 154.8 / 153.7 k)
+#ifndef RF_TAIL_PRIO
+#define RF_TAIL_PRIO 1 // (tests/test_gpu_perf_guard.py was tried on a build with 0: profiles/r05_ab.txt section 5)
+#endif
+constexpr int kTailPrio = RF_TAIL_PRIO;        // s_setprio of the waves inside coop_workers (0 / 1 / 2 / 3: 151.5 / 155.5 / 154.8 / 153.7 k)
 constexpr int kTileH2 = kTileH * kSets;
 
 // A 32-bit value nobody has to compute: the raw-draw words of a sample are written by the first

@@ -58,6 +58,19 @@ def shipped_libraries_match_their_sources():
     yield
 
 
+@pytest.fixture(params=["three pixels per thread", "the library's choice"])
+def kernel_choice(request, monkeypatch):
+    """The render kernels a context created inside the test takes.  The session's default forces the benchmarked kernels at
+    every size (pytest_configure above); a test that names this fixture runs twice -- once like that, once with the
+    switches unset, i.e. with the kernels the library itself picks for the launch (for most test sizes: render_kernel
+    without cooperative tails, and the dense or literal general kernel) -- which is what the reference's default use
+    takes (state_observer.py:335: one 300 x 300 environment; examples/ppo_tuned.yml:5: n_envs 8)."""
+    if request.param == "the library's choice":
+        monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
+        monkeypatch.delenv("REINFOCUS_GENERAL_ONE", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/), built on demand.  Test infrastructure only."""

@@ -23,8 +23,19 @@ def ctx():
     c.close()
 
 
+@pytest.fixture()
+def ctx_choice(kernel_choice):
+    """a context with the session's forced kernels, and one with the library's own choice (conftest.kernel_choice)"""
+    from reinfocus_amd import _native
+
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
 @pytest.mark.parametrize("name", ["general_small", "general_rect"])
-def test_general_golden(ctx, golden_dir, name):
+def test_general_golden(ctx_choice, golden_dir, name):
+    ctx = ctx_choice
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     n, h, w, spp = len(g["sizes"]), int(g["h"]), int(g["w"]), int(g["spp"])
     frames = ctx.render_general(g["cameras"], g["params"], g["types"], g["sizes"], h, w, spp)
@@ -34,7 +45,8 @@ def test_general_golden(ctx, golden_dir, name):
 
 @pytest.mark.parametrize("n,h,w,spp,seed", [(8, 40, 56, 6, 1), (3, 96, 64, 8, 2), (16, 33, 35, 3, 3), (12, 64, 64, 12, 4),
                                            (6, 50, 128, 5, 5), (2, 256, 256, 4, 6)])
-def test_general_random_scenes_match_oracle(ctx, oracle, n, h, w, spp, seed):
+def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, seed):
+    ctx = ctx_choice
     rng = np.random.default_rng(seed)
     cameras, (params, types, sizes) = _random_scene(rng, n)
     st = oracle.seed_states(n * h * w, 0)
@@ -131,7 +143,7 @@ def test_reference_render_tests():
     assert frames.shape == (2, 300, 600, 3)
 
 
-def test_general_equals_fast_path_for_one_rectangle(ctx, oracle):
+def test_general_equals_fast_path_for_one_rectangle(ctx_choice, oracle):
     """One rectangle per env through the general kernel vs the oracle's general path; the
     FastRenderer scene is the same geometry with uf = 32 and a single bounce, so only the
     oracle comparison is exact here."""
@@ -143,9 +155,9 @@ def test_general_equals_fast_path_for_one_rectangle(ctx, oracle):
     p, t, s = worlds.device_data()
     st = oracle.seed_states(2 * 64 * 64, 0)
     want = oracle.render_general(cams.device_data(), p, t, s, 64, 64, 5, st, n_threads=8)
-    got = ctx.render_general(cams.device_data(), p, t, s, 64, 64, 5)
+    got = ctx_choice.render_general(cams.device_data(), p, t, s, 64, 64, 5)
     assert np.array_equal(got, want)
-    assert np.array_equal(ctx.get_states(0, 2 * 64 * 64), st)
+    assert np.array_equal(ctx_choice.get_states(0, 2 * 64 * 64), st)
 
 
 def _random_one_shape_worlds(rng, n, kind="rectangle"):
@@ -392,6 +404,24 @@ def test_a_fix_up_list_that_overflows_is_rendered_again_by_the_literal_kernel(or
     want = oracle.render_general(scene[0], *scene[1], h, w, spp, st, n_threads=16)
     frames, states, redo, kernel = _general_in_child(tmp_path, scene, h, w, spp, {"REINFOCUS_GENERAL_REDO_CAP": "1"})
     assert kernel.startswith("render_general_one_kernel") and redo >= 2, (kernel, redo)
+    assert np.array_equal(frames, want) and np.array_equal(states, st)
+
+
+@pytest.mark.parametrize("kind", ["rectangle", "sphere"])
+@pytest.mark.parametrize("n,h,w,spp", [(3, 128, 128, 6), (3, 100, 100, 6), (2, 64, 256, 5), (2, 90, 300, 4)])
+def test_one_shape_kernel_under_delayed_waves(oracle, tmp_path, kind, n, h, w, spp):
+    """render_general_one_kernel orders its cooperative calls against each other by barriers alone, like the fast path's
+    kernel whose machinery it uses (rf_coop2.h SYNCHRONISATION; tests/test_sync_model.py checks that both spell the same
+    protocol).  The RF_TEST_SKEW build delays one wave of every block -- a different one from call to call -- by ~8 000
+    cycles before it reads a call's counter, before thread 0's resets and before the collect reads: frames and RNG
+    states must still be the oracle's, for both kinds of shape, with in-wave disc tails (power-of-two frames) and with
+    the block-wide disc call (others), in both tile shapes."""
+    so = helpers.built("tests/gpucheck", "libreinfocus_skew.so")
+    scene = _random_one_shape_worlds(np.random.default_rng(n * 10 + h), n, kind)
+    st = oracle.seed_states(n * h * w, 0)
+    want = oracle.render_general(scene[0], *scene[1], h, w, spp, st, n_threads=16)
+    frames, states, _redo, kernel = _general_in_child(tmp_path, scene, h, w, spp, {"REINFOCUS_HIP_LIB": so, "REINFOCUS_GENERAL_ONE": "1"})
+    assert kernel.startswith("render_general_one_kernel"), kernel
     assert np.array_equal(frames, want) and np.array_equal(states, st)
 
 

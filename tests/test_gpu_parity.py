@@ -22,7 +22,9 @@ def native():
 
 
 @pytest.fixture()
-def ctx(native):
+def ctx(native, kernel_choice):
+    """(every test that renders through this context runs with the benchmarked kernels forced and with the library's
+    own choice: conftest.kernel_choice)"""
     c = native.Context(0)
     yield c
     c.close()
@@ -65,7 +67,7 @@ def test_seed_other_seed(ctx, oracle):
 
 
 @pytest.mark.parametrize("name", ["render_pow2", "render_npot", "render_rsize30", "render_cfg1", "render_mid"])
-def test_render_golden(native, golden_dir, name):
+def test_render_golden(native, golden_dir, name, kernel_choice):
     """FastRenderer (HIP) reproduces the numpy-1.26 restatement bit for bit."""
     from reinfocus_amd.graphics import render
 
@@ -278,7 +280,7 @@ def test_focus_of_rendered_frames(ctx, oracle):
 # --- the Python surface ---------------------------------------------------------------------
 
 
-def test_fast_renderer_and_vision_surface(native, oracle):
+def test_fast_renderer_and_vision_surface(native, oracle, kernel_choice):
     """tests/vision_test.py:40-56 of the reference, on the HIP path, plus oracle parity."""
     from reinfocus_amd import vision
     from reinfocus_amd.graphics import render
@@ -310,7 +312,7 @@ def test_vision_known_answers(native):
     assert vision.focus_value(frame) > 1
 
 
-def test_render_known_answers(native):
+def test_render_known_answers(native, kernel_choice):
     """tests/graphics/render_test.py:83-116 of the reference (FastRendererTest)."""
     from reinfocus_amd.graphics import render
 

@@ -1,0 +1,88 @@
+"""A performance guard for the kernels that carry the numbers in profiles/: the fused two-pass instance of the fast path
+(the headline's kernel), the strip kernel of the reference's default 300 x 300 x 100 shape, and the general renderer's
+one-shape and dense kernels.  Each is timed with HIP events on the context's own stream (rf_timing) around a few
+launches at a size that fills the device, and must reach FLOOR x the rate recorded in profiles/r05_perf_guard.json --
+measured by this very test on the round-5 tree (REINFOCUS_PERF_GUARD_RECORD=<file> writes what a run measures).  The kernel
+each launch took is asserted too: a change of the dispatch that sends a shape to another kernel shows up by name.  The
+floor is wide enough for the boxes of the pool (the same build measures within +-1.5 % on different boxes, kernel time),
+and narrow enough for what a careless edit costs: see profiles/r05_ab.txt section 5 for the builds it was tried on."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.test_general_renderer import _factory_worlds
+
+pytestmark = pytest.mark.gpu
+
+RECORD = os.path.join(helpers.ROOT, "profiles", "r05_perf_guard.json")
+FLOOR = 0.95
+
+
+def _measure():
+    from reinfocus_amd import _native
+    from reinfocus_amd.environments import harness
+
+    got = {}
+    # 1. the fused environment step's render: render_kernel_coop2<.., TWO> (1024 x 256^2 x 16, three steps)
+    env = harness.DeviceVectorDiscreteSteps(num_envs=1024, frame_height=256, samples_per_pixel=16, seed=3, device=0)
+    env.reset()
+    rng = np.random.default_rng(1)
+    env.step(rng.integers(0, 13, 1024))  # (warm-up)
+    env._ctx.timing(True)
+    before = _native.pixels_rendered()
+    for _ in range(3):
+        env.step(rng.integers(0, 13, 1024))
+    t = env._ctx.timing_read()
+    pixels = _native.pixels_rendered() - before
+    got["fused_step_1024x256x16"] = {"kernel": env._ctx.render_kernel_name(),
+                                     "g_samples_per_s": pixels * 16 / (t["render_ms"] * 1e-3) / 1e9}
+    env.close()
+    # 2. the strip kernel: 128 x 300^2 x 100
+    ctx = _native.Context(0)
+    n, h, spp = 128, 300, 100
+    ctx.seed(n * h * h, 0, 0)
+    ctx.set_scene(*helpers.pack_scene(*helpers.random_scene(np.random.default_rng(2), n)))
+    ctx.render(n, h, h, spp)
+    ctx.timing(True)
+    for _ in range(3):
+        ctx.render(n, h, h, spp)
+    t = ctx.timing_read()
+    got["strip_128x300x100"] = {"kernel": ctx.render_kernel_name(),
+                                "g_samples_per_s": 3 * n * h * h * spp / (t["render_ms"] * 1e-3) / 1e9}
+    ctx.timing(False)
+    # 3. the general renderer at 64 x 256^2 x 16: one rectangle (the cooperative one-shape kernel), mixed (the dense kernel)
+    from reinfocus_amd.graphics import camera, shape_factory as sf, world
+
+    n, h, spp = 64, 256, 16
+    rng = np.random.default_rng(0)
+    p, ty, si = world.Worlds(*[sf.one_rect(sf.ShapeParameters(float(d))) for d in rng.uniform(5, 10, n)]).device_data()
+    cams = camera.Cameras(*[camera.make_gpu_camera(focus_distance=float(f)) for f in rng.uniform(5, 10, n)]).device_data()
+    scenes = {"general_one_rect_64x256x16": (np.ascontiguousarray(cams, dtype=np.float64), (p, ty, si)),
+              "general_mixed_64x256x16": _factory_worlds(rng, n, "mixed")}
+    for name, (cameras, (params, types, sizes)) in scenes.items():
+        ctx.render_general(cameras, params, types, sizes, h, h, spp, to_host=False)
+        ctx.timing(True)
+        for _ in range(3):
+            ctx.render_general(cameras, params, types, sizes, h, h, spp, to_host=False)
+        t = ctx.timing_read()
+        got[name] = {"kernel": ctx.render_kernel_name(), "g_samples_per_s": 3 * n * h * h * spp / (t["render_ms"] * 1e-3) / 1e9}
+        ctx.timing(False)
+    ctx.close()
+    return got
+
+
+def test_the_kernels_keep_their_names_and_their_speed():
+    got = _measure()
+    if os.environ.get("REINFOCUS_PERF_GUARD_RECORD"):
+        with open(os.environ["REINFOCUS_PERF_GUARD_RECORD"], "w") as out:
+            json.dump(got, out, indent=1)
+    want = json.load(open(RECORD))
+    assert set(got) == set(want["kernels"])
+    for name, reference in want["kernels"].items():
+        assert got[name]["kernel"] == reference["kernel"], (name, got[name]["kernel"])
+        floor = FLOOR * reference["g_samples_per_s"]
+        assert got[name]["g_samples_per_s"] >= floor, (name, got[name]["g_samples_per_s"], "floor", floor)

@@ -188,3 +188,57 @@ def test_the_two_passes_of_the_fused_step_need_no_barrier_of_their_own(in_wave_d
     for outcomes in all_outcomes(2, with_disc=not in_wave_disc):
         found = races(sample_loop(outcomes, in_wave_disc, fenced=True, alternate=True, passes=2))
         assert not found, (outcomes, found[:3])
+
+
+# --- the model against the sources: which synchronisation-relevant steps the kernels take, in which order ---------------
+
+import os
+import re
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reinfocus_amd", "csrc")
+STEPS = [("clear", r"lds\.cnt\[tid\] = 0"), ("barrier", r"__syncthreads\(\)"), ("disc-in-wave", r"disc_tails_wave\(lds\.state\[0\]"),
+         ("disc-call", r"coop_finish2m<2, kWaveSlots, false>\(lds, 0, &lds\.cnt\[0\]"),
+         ("sphere-counter", r"&lds\.cnt\[kDiscInWave \? \(k & 1\) : 1\]"),
+         ("sphere-call", r"coop_finish2m<3, kWaveSlots, kDiscInWave>\(lds, 1, sphere_cnt"),
+         ("stage-write", r"sb\[slot \* 3 \+ 0\] ="), ("stage-read", r"= stage\[r \* kRowDw \+ d\w*\]"),
+         ("own-colour", r"lds_colour\[j\]\[0\]\[tid\] =")]
+
+
+def protocol_steps(header, start, end):
+    """The synchronisation-relevant steps of the code between two markers of a header, in source order."""
+    text = open(os.path.join(CSRC, header)).read()
+    body = text[text.index(start):text.index(end, text.index(start))]
+    body = re.sub(r"//[^\n]*", "", body)  # (comments talk about barriers too)
+    found = []
+    for name, pattern in STEPS:
+        found += [(m.start(), name) for m in re.finditer(pattern, body)]
+    return [name for _, name in sorted(found)]
+
+
+# what sample_loop() above models, as the source has to spell it: counters cleared, barrier, [per sample: the disc phase
+# in one of its two forms, the sphere call on the alternating counter], barrier, stage written, barrier, stage read.
+# (own-colour: the colour sums of two pixel sets live in LDS at the thread's own index: no other thread touches them)
+EXPECTED = ["clear", "barrier", "own-colour", "disc-in-wave", "disc-call", "sphere-counter", "sphere-call", "own-colour", "barrier",
+            "stage-write", "barrier", "stage-read"]
+
+
+def test_the_fast_path_kernel_spells_the_modelled_protocol():
+    got = protocol_steps("rf_coop2.h", "__device__ __forceinline__ void render_tile_coop2(", "template <bool POW2, int LENS, int WX = kWavesX")
+    assert got == EXPECTED, got
+
+
+def test_the_one_shape_general_kernel_spells_the_same_protocol():
+    """render_general_one_kernel (rf_general_one.h) uses the cooperative machinery of rf_coop2.h -- disc_tails_wave or
+    the block-wide disc call, the fenced sphere call on the alternating counter, the frame stage in words4 -- in the
+    same order as render_tile_coop2, so the model checks above cover it; what it adds touches no shared LDS word: the
+    abstention flags are lane masks in scalar registers and a NaN in the thread's own colour sum, the fix-up list is
+    global memory (one atomic per abstaining pixel, read by the next kernel on the stream)."""
+    got = protocol_steps("rf_general_one.h", "render_general_one_kernel(GeneralOneArgs ra)", "// The listed pixels, literally")
+    assert got == EXPECTED, got
+    text = open(os.path.join(CSRC, "rf_general_one.h")).read()
+    body = text[text.index("render_general_one_kernel(GeneralOneArgs ra)"):text.index("// The listed pixels, literally")]
+    assert "__shared__ CoopLds2 lds;" in body and body.count("__shared__") == 2  # (the cooperative arrays + the own colour sums)
+    assert "redo_append(ra," in body and "atomicAdd(&lds" not in body
+    for in_wave_disc in (True, False):  # the two instances (power-of-two frames / others), single pass
+        for outcomes in all_outcomes(3, with_disc=not in_wave_disc):
+            assert not races(sample_loop(outcomes, in_wave_disc, fenced=True, alternate=True))
