@@ -13,9 +13,13 @@ enders / rewards, scene packing, the render kernel, the focus kernel, an 8 B/env
 same-step partial render of the environments that just ended.
 Workload = BASELINE.json configs[2]: 4096 envs x 256x256 x 16 spp per GPU; with N > 1 every rank
 owns 4096 more envs (weak scaling, BASELINE configs[3]) and its own slice of the RNG state
-sequence.  There is no data-path collective: environments are independent, ranks only meet at
-the timing barriers (gloo, host side).  --sharded-env measures the product-level object instead
-(harness.ShardedVectorDiscreteSteps: one process, one rf_ctx + one host thread per GPU).
+sequence.  There is no data-path collective: environments are independent.  What the one vector
+environment the ranks stand for returns from step() -- ONE obs[N, 4], rewards[N], flags[N]
+(vector_environment.py:104-164) -- is put together on the host: every step, inside the timed
+region, rank 0 gathers the ranks' blocks (29 B/env) over gloo; otherwise the ranks meet only at the
+timing barriers.  --sharded-env measures the product-level object instead
+(harness.ShardedVectorDiscreteSteps: one process, one rf_ctx + one host thread per GPU, step()
+concatenates).
 
 Prints ONE JSON line (rank 0).  value = all ranks' env-steps / max-over-ranks seconds, with
 inputs resident in HBM (the only per-step host traffic is 4 + 8 B/env of actions and candidate
@@ -229,6 +233,32 @@ class Ranks:
         items = [None] * self.world
         self.dist.all_gather_object(items, item)
         return items
+
+    STEP_BYTES_PER_ENV = 29  # observations float32 x 4, reward float64, terminated, truncated, ... : harness's per-env output
+
+    def gather_step(self, obs, rewards, terminated, truncated):
+        """What one environment over all ranks' ranges returns from step() is ONE obs[N, 4] / rewards[N] / flags[N]
+        (vector_environment.py:104-164): rank 0 receives every rank's block -- 29 B per environment over gloo, the
+        host-side gather north_star allows -- inside the timed region.  Returns the bytes rank 0 holds afterwards."""
+        n = len(rewards)
+        if self.dist is None:
+            return n * self.STEP_BYTES_PER_ENV
+        import torch
+
+        block = np.empty((n, self.STEP_BYTES_PER_ENV), dtype=np.uint8)
+        block[:, 0:16] = np.ascontiguousarray(obs, dtype=np.float32).reshape(n, 4).view(np.uint8)
+        block[:, 16:24] = np.ascontiguousarray(rewards, dtype=np.float64).reshape(n, 1).view(np.uint8)
+        block[:, 24] = terminated
+        block[:, 25] = truncated
+        block[:, 26:] = 0
+        mine = torch.from_numpy(block)
+        if self.rank == 0:
+            if getattr(self, "_gathered", None) is None or self._gathered[0].shape != mine.shape:
+                self._gathered = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.gather(mine, self._gathered, dst=0)
+            return sum(int(t.numel()) for t in self._gathered)
+        self.dist.gather(mine, None, dst=0)
+        return 0
 
     def close(self):
         if self.dist is not None:
@@ -650,12 +680,19 @@ def main(argv=None):
         raise SystemExit("bench.py: " + shared_gpu)
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
+    gathered_bytes = [0]
+
     def one_step():
         actions = action_rng.integers(0, 13, n_here)
-        if env is None:
+        if env is None:  # (plumbing: a fake block goes through the same gather)
             time.sleep(0.002)
+            gathered_bytes[0] = ranks.gather_step(np.zeros((n_here, 4), np.float32), np.zeros(n_here), np.zeros(n_here, bool),
+                                                  np.ones(n_here, bool))
             return 0
-        _, _, term, trunc, _ = env.step(actions)
+        obs, rewards, term, trunc, _ = env.step(actions)
+        # one process per GPU: the ranks' blocks are gathered on rank 0, as the one vector environment they stand for would
+        # return them (the sharded product object concatenates inside step() itself)
+        gathered_bytes[0] = ranks.gather_step(obs, rewards, term, trunc)
         return int((term | trunc).sum())
 
     for _ in range(args.warmup):
@@ -723,9 +760,13 @@ def main(argv=None):
                 "frame": frame,
                 "spp": spp,
                 "auto_resets_per_step": total_resets / max(args.steps, 1),
-                "sharding": ("one process, one rf_ctx + host thread per GPU (ShardedVectorDiscreteSteps)"
-                             if args.sharded_env else "one process per GPU, independent env ranges") +
+                "sharding": ("one process, one rf_ctx + host thread per GPU (ShardedVectorDiscreteSteps): step() returns the "
+                             "concatenated arrays" if args.sharded_env else
+                             "one process per GPU, contiguous env ranges; every step's observations / rewards / flags gathered "
+                             "on rank 0 over gloo inside the timed region") +
                             ", no data-path collective",
+                # what rank 0 holds after a step: N x 29 B (value = all ranks' environments / the time to step AND gather them)
+                "host_gather_bytes_per_step": gathered_bytes[0],
                 "env_glue": {"device": "device-resident (rf_env_step)", "host": "host numpy (harness), frames stay in HBM",
                              "literal": "host numpy (harness) over the literal stub: rf_render(host_out) + "
                                         "rf_upload_frames + rf_focus, frames cross PCIe twice per render"}[args.env],

@@ -37,6 +37,7 @@ def test_single_rank_plumbing_line():
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
     assert line["value"] is None and "plumbing" in line["data"]
     assert line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["config"]["host_gather_bytes_per_step"] == 29 * line["config"]["total_envs"]  # (one rank: its own block)
 
 
 def test_two_ranks_over_gloo():
@@ -46,6 +47,10 @@ def test_two_ranks_over_gloo():
     assert line["n_gpus"] == 2
     assert line["config"]["total_envs"] == 2 * line["config"]["envs_per_gpu"]
     assert line["ms_per_step"] > 0
+    # every step's block of every rank (29 B per environment) is gathered on rank 0 inside the timed region: one vector
+    # environment over all ranges returns ONE obs[N, 4] (vector_environment.py:104-164)
+    assert line["config"]["host_gather_bytes_per_step"] == 29 * line["config"]["total_envs"]
+    assert "gathered on rank 0" in line["config"]["sharding"]
 
 
 def test_bench_launches_its_own_ranks():
