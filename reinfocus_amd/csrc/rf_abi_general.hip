@@ -205,12 +205,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             d.redo_list = (unsigned *)(scratch + o_lst);
             d.redo_cap = (unsigned)cap;
             d.shapes = (const rf::ShapeConst *)(scratch + o_shp) + (size_t)e0 * most;
-            d.w64 = (double)w;
-            d.h64 = (double)h;
-            d.rw64 = 1.0 / (double)w;
-            d.rh64 = 1.0 / (double)h;
-            d.inv_w = 1.0f / (float)w;
-            d.inv_h = 1.0f / (float)h;
+            d.fc = rf::frame_const(h, w);
             const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
             const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
             if (kind == kDense) {

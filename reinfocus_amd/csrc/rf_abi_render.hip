@@ -126,12 +126,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
     a.hw = h * w;
     a.scale = (float)(255.0 / (double)spp);
     const bool pow2 = is_pow2(h) && is_pow2(w);
-    a.inv_w = 1.0f / (float)w;
-    a.inv_h = 1.0f / (float)h;
-    a.rw64 = 1.0 / (double)w;
-    a.rh64 = 1.0 / (double)h;
-    a.w64 = (double)w;
-    a.h64 = (double)h;
+    a.fc = rf::frame_const(h, w);
     a.count2 = second ? second->count : nullptr;
     a.cam_dyn2 = second ? second->cam : nullptr;
     a.rect2 = second ? second->rect : nullptr;

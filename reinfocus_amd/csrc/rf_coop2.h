@@ -593,8 +593,7 @@ __device__ __forceinline__ void render_tile_coop2(const RenderArgs &a_in, CoopLd
         for (int j = 0; j < kSets; ++j) {
             // ((float)y of the further sets by an exact float addition: conversions issue on the slow path)
             sample_coords<POW2>(g[j], gk.x_of(j), gk.y_of(j), ACROSS ? (float)gk.x + (float)(j * tDx) : (float)gk.x,
-                                ACROSS ? (float)gk.y0 : (float)gk.y0 + (float)(j * tDy), a.h64, a.w64, a.inv_w, a.inv_h,
-                                a.rw64, a.rh64, s[j], t[j]);
+                                ACROSS ? (float)gk.y0 : (float)gk.y0 + (float)(j * tDy), a.fc, s[j], t[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 w[j][i] = any_u32();

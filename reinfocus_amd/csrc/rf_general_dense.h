@@ -352,7 +352,7 @@ RF_UNROLL
 // one pixel of device_render (render.py:31-85); false: the pixel abstains (g, cr, cg, cb are then meaningless)
 template <bool POW2, int NS, class Cam, class Shapes>
 RF_HD bool render_pixel_dense(Rng &g, int x, int y, int spp, const Cam &cam, float lens_hi, float lens_lo,
-                              const Shapes *sc, float inv_w, float inv_h, double w64, double h64, double rw64, double rh64,
+                              const Shapes *sc, const FrameConst &fc,
                               float &cr, float &cg, float &cb)
 {
     cr = cg = cb = 0.0f;
@@ -360,7 +360,7 @@ RF_HD bool render_pixel_dense(Rng &g, int x, int y, int spp, const Cam &cam, flo
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, h64, w64, inv_w, inv_h, rw64, rh64, s, t); // render.py:61-66
+        sample_coords<POW2>(g, x, y, xf, yf, fc, s, t); // render.py:61-66
         float p0, p1;
         disc_sample(g, p0, p1);
         float o[3], d[3];

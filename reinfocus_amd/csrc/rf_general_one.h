@@ -45,8 +45,7 @@ struct GeneralOneArgs {
     unsigned redo_cap;    // entries the list holds; a launch that abstains more often is rendered again by the literal
                           // kernel from fresh states (rf_abi_general.hip)
     const ShapeConst *shapes; // [n][NS] (render_general_dense_kernel)
-    double w64, h64, rw64, rh64; // frame sizes and their reciprocals (pixel_coord_div); inv_w / inv_h for POW2
-    float inv_w, inv_h;
+    FrameConst fc; // frame sizes in the forms the jittered coordinates use (rf_math.h)
 };
 
 // a pixel that abstains: counted always, listed while the list has room
@@ -222,8 +221,7 @@ render_general_one_kernel(GeneralOneArgs ra)
 #pragma unroll
         for (int j = 0; j < kSets; ++j) {
             // render.py:61-66 (the x coordinate's draw first): sample_coords is general_coords for frames up to 4096
-            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y0 + (float)(j * tTileH), ra.h64, ra.w64,
-                                ra.inv_w, ra.inv_h, ra.rw64, ra.rh64, s[j], t[j]);
+            sample_coords<POW2>(g[j], gk.x, gk.y_of(j), (float)gk.x, (float)gk.y0 + (float)(j * tTileH), ra.fc, s[j], t[j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 w[j][i] = any_u32();
@@ -524,8 +522,7 @@ __global__ __launch_bounds__(kBlock, kDenseOcc) void render_general_dense_kernel
         const_as<GeneralCamera> &cam = *as_const(a.cameras + e);
         const_as<ShapeConst> *const sc = as_const(ra.shapes + (size_t)e * NS);
         float cr, cg, cb;
-        const bool keep = render_pixel_dense<POW2, NS>(g, x, y, a.spp, cam, cam.lens_hi, cam.lens_lo, sc, ra.inv_w, ra.inv_h,
-                                                       ra.w64, ra.h64, ra.rw64, ra.rh64, cr, cg, cb);
+        const bool keep = render_pixel_dense<POW2, NS>(g, x, y, a.spp, cam, cam.lens_hi, cam.lens_lo, sc, ra.fc, cr, cg, cb);
         if (keep) {
             a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
             r8 = (uint8_t)(cr * a.scale);

@@ -749,29 +749,58 @@ RF_HD Colour sample_axis(Rng &g, const PixelEnv &e, const CamStatic &cs, float s
     return sample_axis_shade(r, q0, q1, q2);
 }
 
+// what the jittered coordinates need to know about the frame, computed once on the host (kernel arguments: scalar
+// registers, no per-lane conversions)
+struct FrameConst {
+    double w64, h64;    // (double)w, (double)h
+    double rw64, rh64;  // RN64(1 / w), RN64(1 / h): pixel_coord_div
+    float inv_w, inv_h; // 1 / w, 1 / h: exact for powers of two (pixel_coord_pow2)
+};
+
+RF_HD FrameConst frame_const(int h, int w)
+{
+    FrameConst f;
+    f.w64 = (double)w;
+    f.h64 = (double)h;
+    f.rw64 = 1.0 / f.w64;
+    f.rh64 = 1.0 / f.h64;
+    f.inv_w = 1.0f / (float)w;
+    f.inv_h = 1.0f / (float)h;
+    return f;
+}
+
 // jittered pixel coordinates of one sample (render.py:229-234), two draws
 template <bool POW2>
-RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, double h64, double w64, float inv_w, float inv_h,
-                         double rw64, double rh64, float &s, float &t)
+RF_HD void sample_coords(Rng &g, int x, int y, float xf, float yf, const FrameConst &f, float &s, float &t)
 {
     uint32_t xh, xl, yh, yl;
     rng_next(g, xh, xl);
     rng_next(g, yh, yl);
     const float xi = unit_f32_scaled64(xh, xl), yi = unit_f32_scaled64(yh, yl); // 2^64 * uniform
-    s = POW2 ? pixel_coord_pow2_64(xf, xi, inv_w) : pixel_coord_div(x, xi * kTwoM64, w64, rw64);
-    t = POW2 ? pixel_coord_pow2_64(yf, yi, inv_h) : pixel_coord_div(y, yi * kTwoM64, h64, rh64);
+    if (POW2) {
+        s = pixel_coord_pow2_64(xf, xi, f.inv_w);
+        t = pixel_coord_pow2_64(yf, yi, f.inv_h);
+        return;
+    }
+    // other frame sizes: the float64 quotient, seven instructions per coordinate.  (A double-float form in float32 --
+    // two_sum, quotient, exact residual, correction, with the float64 form only next to rounding boundaries and for
+    // jitters too small for x + xi to be exact -- is bit-identical too (10^9 quotients on the CPU, the GPU suite) and 2-4 %
+    // SLOWER end to end: thirteen float32 operations and two compares do not hide behind the generator's integer work:
+    // profiles/r05_ab.txt section 7.)
+    s = pixel_coord_div(x, xi * kTwoM64, f.w64, f.rw64);
+    t = pixel_coord_div(y, yi * kTwoM64, f.h64, f.rh64);
 }
 
 template <bool AXIS, bool POW2>
-RF_HD void render_pixel(Rng &g, int x, int y, int h, int w, int spp, float inv_w, float inv_h, double rw64,
-                        double rh64, const PixelEnv &e, const CamStatic &cs, const CheckerTable &tab, float &cr,
+RF_HD void render_pixel(Rng &g, int x, int y, int spp, const FrameConst &f, const PixelEnv &e, const CamStatic &cs,
+                        const CheckerTable &tab, float &cr,
                         float &cg, float &cb)
 {
     cr = cg = cb = 0.0f;
     const float xf = (float)x, yf = (float)y;
     for (int k = 0; k < spp; ++k) {
         float s, t;
-        sample_coords<POW2>(g, x, y, xf, yf, (double)h, (double)w, inv_w, inv_h, rw64, rh64, s, t);
+        sample_coords<POW2>(g, x, y, xf, yf, f, s, t);
         Colour c = AXIS ? sample_axis(g, e, cs, s, t, tab)
                         : sample_general(g, e.dyn, cs, e.rect, s, t, tab);
         cr = add2(cr, c.r);

@@ -19,9 +19,7 @@ struct RenderArgs {
     int n, h, w, spp;
     int hw;          // h*w
     float scale;     // float32(255.0 / spp)   (render.py:244-246)
-    float inv_w, inv_h; // exact reciprocals when w / h are powers of two
-    double rw64, rh64;  // RN64(1 / w), RN64(1 / h) for pixel_coord_div
-    double w64, h64;    // (double)w, (double)h: scalar operands, no per-lane conversions
+    FrameConst fc;   // frame sizes in the forms the jittered coordinates use (rf_math.h)
     // render_kernel_coop2<..., TWO = true> (the environment step as one launch, rf_abi.hip enqueue_env_step_fused): the
     // blocks of the environments below *count2 render their tile twice -- the step's frame into frames2, then the scene
     // cam_dyn2 / rect2 of the same slot into frames, continuing the pixels' RNG streams (vector_environment.py:137-151:
@@ -64,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderArgs a)
         float cr = 0.0f, cg = 0.0f, cb = 0.0f;
         if (live) {
             const PixelEnv env = make_pixel_env(cam + (size_t)e * 9, rect + (size_t)e * 2);
-            render_pixel<AXIS, POW2>(g, x, y, a.h, a.w, a.spp, a.inv_w, a.inv_h, a.rw64, a.rh64, env, a.cs, a.tab, cr, cg, cb);
+            render_pixel<AXIS, POW2>(g, x, y, a.spp, a.fc, env, a.cs, a.tab, cr, cg, cb);
         }
 
         // uint8 truncation of float32(colour * scale)   (render.py:244-246)

@@ -43,8 +43,7 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
     cs.lens_lo = (float)(lens_radius - (double)cs.lens_hi);
     cs.lens_f32 = (mode >> 2) & 1; // bit 2: the float32 lens offset (the caller has checked the radius)
     const float scale = (float)(255.0 / (double)spp);
-    const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
-    const double rw64 = 1.0 / (double)w, rh64 = 1.0 / (double)h;
+    const FrameConst fc = frame_const(h, w);
     for (int e = 0; e < n; ++e) {
         const PixelEnv env = make_pixel_env(cam_dyn + 9 * e, rect + 2 * e);
         for (int y = 0; y < h; ++y)
@@ -53,10 +52,10 @@ int hs_render(uint8_t *frames, int n, int h, int w, int spp, const float *cam_dy
                 Rng g = rng_load(states[2 * pix], states[2 * pix + 1]);
                 float cr, cg, cb;
                 switch (mode & 3) {
-                case 3: render_pixel<true, true>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
-                case 1: render_pixel<true, false>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
-                case 2: render_pixel<false, true>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
-                default: render_pixel<false, false>(g, x, y, h, w, spp, inv_w, inv_h, rw64, rh64, env, cs, tab, cr, cg, cb); break;
+                case 3: render_pixel<true, true>(g, x, y, spp, fc, env, cs, tab, cr, cg, cb); break;
+                case 1: render_pixel<true, false>(g, x, y, spp, fc, env, cs, tab, cr, cg, cb); break;
+                case 2: render_pixel<false, true>(g, x, y, spp, fc, env, cs, tab, cr, cg, cb); break;
+                default: render_pixel<false, false>(g, x, y, spp, fc, env, cs, tab, cr, cg, cb); break;
                 }
                 states[2 * pix] = rng_s0(g);
                 states[2 * pix + 1] = rng_s1(g);
@@ -466,6 +465,7 @@ int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const
     const bool pow2 = h > 0 && w > 0 && (h & (h - 1)) == 0 && (w & (w - 1)) == 0;
     if (most < 1 || most > 2 || h > 4096 || w > 4096)
         return -1;
+    const FrameConst fc = frame_const(h, w);
     for (int e = 0; e < n; ++e) {
         if (sizes[e] != most)
             return -1;
@@ -484,8 +484,7 @@ int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const
                 float cr, cg, cb;
                 rf::g_dense_perturb = perturb ? (perturb + (unsigned)pix * 2654435761u) | 1u : 0u;
                 bool keep;
-#define HS_DENSE(P, N) keep = render_pixel_dense<P, N>(g, x, y, spp, cam, cam.lens_hi, cam.lens_lo, sc, 1.0f / (float)w, \
-                                                       1.0f / (float)h, (double)w, (double)h, 1.0 / (double)w, 1.0 / (double)h, cr, cg, cb)
+#define HS_DENSE(P, N) keep = render_pixel_dense<P, N>(g, x, y, spp, cam, cam.lens_hi, cam.lens_lo, sc, fc, cr, cg, cb)
                 if (pow2 && most == 1) HS_DENSE(true, 1);
                 else if (pow2) HS_DENSE(true, 2);
                 else if (most == 1) HS_DENSE(false, 1);
