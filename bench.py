@@ -305,7 +305,7 @@ def committed_profile(kernel, frame, spp):
 
 def committed_static_mix(kernel):
     """The static VALU mix by gfx950 issue class that profiles/summarize.py stored for this kernel instance
-    (newest round first), or None: what issue rate this instruction mix can reach."""
+    (newest round first), or None: what issue rate this instruction mix can reach (see DESIGN.md 4.1 "Roofline")."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):

@@ -77,7 +77,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     for (int e = 0; e < n; ++e)
         cams[(size_t)e] = rf::general_camera(cameras + (size_t)e * 19);
 
-    // Which kernel (all bit-identical; DESIGN.md section 4):
+    // Which kernel (all bit-identical; DESIGN.md section 3):
     //  * kOne: worlds of exactly one shape per environment, the same kind in all of them, in launches that fill the device
     //    (more than 2 M pixels with a rectangle, 3 M with a sphere): the cooperative kernel of rf_general_one.h.  The
     //    notebooks' one or two environments are a few hundred blocks, bound by the latency of a sample, where a kernel

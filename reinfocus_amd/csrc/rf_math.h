@@ -60,7 +60,7 @@ RF_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, uint32_t s)
 
 // result = s0 + s1 (as two words), then the xoroshiro128+ 55/14/36 state update:
 // one v_lshl_add_u64 for the sum, v_alignbit_b32 funnel shifts for everything else
-// (13 VALU instructions; checked in the ISA).
+// (10 VALU instructions; checked in the ISA, see profiles/HISTORY.md section 4.1).
 RF_HD void rng_next(Rng &g, uint32_t &r_hi, uint32_t &r_lo)
 {
     const uint32_t a_lo = g.a_lo, a_hi = g.a_hi, b_lo = g.b_lo, b_hi = g.b_hi;
@@ -582,7 +582,7 @@ RF_HD float pixel_coord_div(int x, float xi, double w, double rw)
 }
 
 // For w a power of two the same value needs no f64: the f64 sum is either exact or
-// the addend is < 2^-28 ulp-wise irrelevant, so RN32(RN64(x+xi)) ==
+// the addend is < 2^-28 ulp-wise irrelevant (profiles/HISTORY.md section 4.1), so RN32(RN64(x+xi)) ==
 // RN32(x+xi) == the f32 add, and the division is an exact scaling.
 RF_HD float pixel_coord_pow2(int x, float xi, float inv_w)
 {
