@@ -199,12 +199,8 @@ int rf_create(int device, rf_ctx **out)
         ctx->env_fused = strcmp(v, "0") != 0;
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))
         ctx->env_graph_enabled = v[0] != '0';
-    if (const char *v = getenv("REINFOCUS_TILE_LAYOUT"))
-        ctx->tile_layout = (v[0] >= '0' && v[0] <= '5') ? v[0] - '0' : -1;
     if (const char *v = getenv("REINFOCUS_GENERAL_ONE"))
         ctx->general_one = v[0] != '0', ctx->general_one_always = v[0] == '1';
-    if (const char *v = getenv("REINFOCUS_FOCUS_QUAD"))
-        ctx->focus_quad = v[0] != '0';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
         ctx->env_graph_fail_once = v[0] == '1';
     if (const char *v = getenv("REINFOCUS_ENV_ONE_SYNC_MAX")) {

@@ -82,31 +82,32 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     //    (more than 2 M pixels with a rectangle, 3 M with a sphere): the cooperative kernel of rf_general_one.h.  The
     //    notebooks' one or two environments are a few hundred blocks, bound by the latency of a sample, where a kernel
     //    without barriers is up to three times faster (profiles/r04_ab.txt section 19).
-    //  * kDense: one or two shapes in every environment, cameras with simple axes and a lens radius whose float32 offset is
-    //    exact, frames the quick pixel coordinates are proven for: the float32 kernel with abstentions (rf_general_dense.h).
-    //  * kLiteral: everything else.
+    //  * kDense: at most three shapes per environment, frames the quick pixel coordinates are proven for: the float32 kernel
+    //    with abstentions (rf_general_dense.h) -- its SIMPLE instances when every camera has canonical axes and a lens radius
+    //    whose float32 offset is exact, the ones with the reference's float64 lens products otherwise.
+    //  * kLiteral: everything else (more shapes, frames beyond 4096 pixels).
     enum { kLiteral, kOne, kDense } kind = kLiteral;
     const bool quick_frame = h <= 4096 && w <= 4096;
-    bool uniform_count = most <= 2;
+    bool uniform_count = true;
     for (int e = 0; uniform_count && e < n; ++e)
         uniform_count = sizes[e] == most;
     const bool one_sphere = types[0] == 0;
+    bool simple_cameras = false;
     bool one_shape = ctx->general_one && quick_frame && uniform_count && most == 1 &&
                      (ctx->general_one_always || pixels > (one_sphere ? 3000000u : 2000000u));
     for (int e = 0; one_shape && e < n; ++e)
         one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
     if (one_shape) {
         kind = kOne;
-    } else if (ctx->general_dense && quick_frame && uniform_count) {
-        bool simple = true;
-        for (int e = 0; simple && e < n; ++e) {
+    } else if (ctx->general_dense && quick_frame && most <= 3) {
+        kind = kDense;
+        simple_cameras = true;
+        for (int e = 0; simple_cameras && e < n; ++e) {
             rf::CamStatic probe{};
             probe.lens_radius = cams[(size_t)e].lens_radius;
             lens_split(probe); // (remembered per radius)
-            simple = probe.lens_f32 != 0 && rf::camera_axes_simple(cams[(size_t)e]);
+            simple_cameras = probe.lens_f32 != 0 && rf::camera_axes_simple(cams[(size_t)e]);
         }
-        if (simple)
-            kind = kDense;
     }
     const bool listed = kind != kLiteral;
 
@@ -143,8 +144,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     std::vector<rf::ShapeConst> shapes;
     if (kind == kDense) {
         shapes.resize((size_t)n * most);
-        for (size_t i = 0; i < shapes.size(); ++i)
-            shapes[i] = rf::shape_const(params + i * width, width, types[i]);
+        for (size_t i = 0; i < shapes.size(); ++i) // (rows beyond an environment's count are never read by the kernel)
+            shapes[i] = rf::shape_const(params + i * width, width, (int)(i % (size_t)most) < sizes[i / (size_t)most] ? types[i] : 1);
     }
     RF_HIP(hipMemcpyAsync(scratch, cams.data(), b_cam, hipMemcpyHostToDevice, ctx->stream));
     RF_HIP(hipMemcpyAsync(scratch + o_par, params, b_par, hipMemcpyHostToDevice, ctx->stream));
@@ -216,23 +217,27 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                 const uint64_t per_env = tiled ? tiles : (uint64_t)gx;
                 RF_REQUIRE(per_env * (uint64_t)ne < (1ull << 31), "rf_render_general: too many blocks for one launch");
                 const dim3 grid_t((unsigned)(per_env * (uint64_t)ne)); // (the environment is the fastest index)
-#define RF_LAUNCH_DENSE_T(P, NS, T)                                                                                      \
+#define RF_LAUNCH_DENSE_TS(P, NS, T, S)                                                                                   \
     do {                                                                                                               \
-        hipLaunchKernelGGL((rf::render_general_dense_kernel<P, NS, T>), grid_t, dim3(rf::kBlock), 0, ctx->stream, d);   \
+        hipLaunchKernelGGL((rf::render_general_dense_kernel<P, NS, T, S>), grid_t, dim3(rf::kBlock), 0, ctx->stream, d); \
         hipLaunchKernelGGL(rf::render_general_fixup_kernel<P>, fix, dim3(rf::kBlock), 0, ctx->stream, d);             \
-        ctx->render_kernel = "render_general_dense_kernel<" #P ", " #NS ", " #T ">";                                   \
+        ctx->render_kernel = "render_general_dense_kernel<" #P ", " #NS ", " #T ", " #S ">";                           \
     } while (0)
 #define RF_LAUNCH_DENSE(P, NS)                                                                                          \
     do {                                                                                                               \
-        if (tiled) RF_LAUNCH_DENSE_T(P, NS, true);                                                                     \
-        else RF_LAUNCH_DENSE_T(P, NS, false);                                                                          \
+        if (tiled && simple_cameras) RF_LAUNCH_DENSE_TS(P, NS, true, true);                                            \
+        else if (tiled) RF_LAUNCH_DENSE_TS(P, NS, true, false);                                                        \
+        else if (simple_cameras) RF_LAUNCH_DENSE_TS(P, NS, false, true);                                               \
+        else RF_LAUNCH_DENSE_TS(P, NS, false, false);                                                                  \
     } while (0)
                 if (pow2 && most == 1) RF_LAUNCH_DENSE(true, 1);
-                else if (pow2) RF_LAUNCH_DENSE(true, 2);
+                else if (pow2 && most == 2) RF_LAUNCH_DENSE(true, 2);
+                else if (pow2) RF_LAUNCH_DENSE(true, 3);
                 else if (most == 1) RF_LAUNCH_DENSE(false, 1);
-                else RF_LAUNCH_DENSE(false, 2);
+                else if (most == 2) RF_LAUNCH_DENSE(false, 2);
+                else RF_LAUNCH_DENSE(false, 3);
 #undef RF_LAUNCH_DENSE
-#undef RF_LAUNCH_DENSE_T
+#undef RF_LAUNCH_DENSE_TS
                 continue;
             }
             // tiles of 128 x 6 or of 64 x 12, whichever leaves fewer dead columns

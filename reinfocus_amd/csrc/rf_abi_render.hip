@@ -17,7 +17,7 @@ namespace {
 // Tile layout of render_kernel_coop2 for a frame size (index into the table in launch_render):
 //   0: 128 x 6 (4 waves of 32 x 2 side by side)   1: 64 x 12 (2 x 2 such waves)
 //   2: 256 x 3 (4 waves of 64 x 1)                3: 128 x 6 (2 x 2 waves of 64 x 1)
-//   4: 64 x 12 (4 waves of 16 x 4 side by side)   5: 32 x 24 (2 x 2 such waves; experiments only)
+//   4: 64 x 12 (4 waves of 16 x 4 side by side)
 // Cost model fitted to tools/ablayout.sh (G samples/s at 128 / 256 / 300 / 384 / 512 / 600 px):
 // time ~ padded area x shape factor x (1 + 0.35 x share of tile columns that lie entirely
 // inside the target).  Such tiles have more stragglers than the 256-entry cooperative list holds
@@ -156,9 +156,9 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             // A block's tile is WX waves of WW x 64/WW pixels side by side, 4/WX down, kSets sets:
             //   A 128 x 6  (WX 4, WW 32)   B 64 x 12 (2, 32)   C 256 x 3 (4, 64)   D 128 x 6 (2, 64)
             // see pick_tile_layout.
-            const int layout = ctx->tile_layout >= 0 ? ctx->tile_layout : pick_tile_layout(h, w, ctx->hit_fraction);
-            static const int kLayoutWX[6] = {4, 2, 4, 2, 4, 2};
-            static const int kLayoutWW[6] = {32, 32, 64, 64, 16, 16};
+            const int layout = pick_tile_layout(h, w, ctx->hit_fraction);
+            static const int kLayoutWX[5] = {4, 2, 4, 2, 4};
+            static const int kLayoutWW[5] = {32, 32, 64, 64, 16};
             const int layout_w = kLayoutWX[layout] * kLayoutWW[layout],
                       layout_h = (4 / kLayoutWX[layout]) * (64 / kLayoutWW[layout]) * rf::kSets;
             const dim3 tiles2(((w + layout_w - 1) / layout_w) * ((h + layout_h - 1) / layout_h), ne);
@@ -169,7 +169,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
             // (measured: +4.0 % at 300 px, +2.1 ... 2.4 % at 200 / 400 / 600 px; at 100 px the 16 x 4 pixel waves of
             // layout 4 are 12 % faster than a 64-column main part: profiles/r04_ab.txt section 17)
             const int rem = w % 64;
-            if (axis && form == 3 && ctx->strip && ctx->tile_layout < 0 && !pow2 && w > 128 && rem > 0 &&
+            if (axis && form == 3 && ctx->strip && !pow2 && w > 128 && rem > 0 &&
                 rem <= 48) {
                 b.strip_x0 = w - rem;
                 const bool wide = b.strip_x0 % 128 == 0; // main tiles of 128 x 6 where they fit, else 64 x 12 (+0.8 % at 300 px)
@@ -209,8 +209,7 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
         case 1: RF_LAUNCH2_ONE(P, L, 2, 32); break;                                                        \
         case 2: RF_LAUNCH2_ONE(P, L, 4, 64); break;                                                        \
         case 3: RF_LAUNCH2_ONE(P, L, 2, 64); break;                                                        \
-        case 4: RF_LAUNCH2_ONE(P, L, 4, 16); break;                                                        \
-        default: RF_LAUNCH2_ONE(P, L, 2, 16); break;                                                       \
+        default: RF_LAUNCH2_ONE(P, L, 4, 16); break;                                                       \
         }                                                                                                  \
     } while (0)
                 if (pow2 && lens32)
@@ -283,7 +282,7 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
 {
     // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
     const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
-    const bool quad = (w & 3) == 0 && w >= 4 && lds_quad <= 64 * 1024 && ctx->focus_quad;
+    const bool quad = (w & 3) == 0 && w >= 4 && lds_quad <= 64 * 1024;
     const int band = quad ? rf::kBandQ : rf::kBand;
     const size_t lds = quad ? lds_quad : ((((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15);
     RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);

@@ -11,10 +11,11 @@
 // literal code from the untouched state.  Abstaining is always safe; a sample that does not abstain has taken, at every
 // comparison and at every rounding to float32, the branch / the value the reference's float64 expression takes:
 //
-//   * camera.get_ray (camera.py:307-350).  The host admits a launch only if every camera's u and v have components in
-//     {0, +1, -1} and the float32 form of the lens offset is exact for its radius (rf_abi_ctx.hip lens_split tries every
-//     disc coordinate): float32(float64(u_k) * (float64(p) * radius)) is then +-lens_offset(p) or +-0 -- exactly what
-//     u_k * lens_offset(p) is in float32.  Other cameras take the literal kernel.
+//   * camera.get_ray (camera.py:307-350).  SIMPLE instances: every camera's u and v have components in {0, +1, -1} and the
+//     float32 form of the lens offset is exact for its radius (rf_abi_ctx.hip lens_split tries every disc coordinate):
+//     float32(float64(u_k) * (float64(p) * radius)) is then +-lens_offset(p) or +-0 -- exactly what u_k * lens_offset(p) is
+//     in float32.  Other cameras (tilted axes, other radii) take the instances with the reference's float64 lens products,
+//     sixteen inline instructions with nothing to decide.
 //   * sphere.hit (sphere.py:40-103).  a, b, c and the discriminant are the reference's float32 expressions.  A negative
 //     discriminant and the certain miss of rf_general.h are exact decisions.  Otherwise root = (-b -+ sqrt(disc)) / a is
 //     evaluated in double-float with a relative error below 2^-43 (bound and measurement: sphere_root_df below); the
@@ -27,10 +28,11 @@
 //     where the literal code would consult float64.
 //   * the sky is float32 in every kernel (rf_math.h: proven equal to the float64 chain).
 //
-// NS: shapes per environment (1 or 2: what the reference's shape factories build).  The shapes' rows and what the kernel
+// NS: the most shapes an environment of the launch holds (1 ... 3; the reference's shape factories build one or two); an
+// environment with fewer leaves the loop early (its count is block-uniform).  The shapes' rows and what the kernel
 // derives from them per shape (radius^2, float32(1 / radius), texture extents and their reciprocals) come from the host as
 // one 64-byte record per shape, read through the constant address space into scalar registers: the bounce loop has no
-// memory access.  Worlds of more shapes, or of different counts in different environments, take the literal kernel.
+// memory access.  Worlds of more than three shapes take the literal kernel.
 #pragma once
 
 #include "rf_general.h"
@@ -298,6 +300,19 @@ RF_HD bool rectangle_red_dense(const float *rp, const float *k, float px, float 
     return checker_sign_dense(rp[5], u, doubt) * checker_sign_dense(rp[6], v, doubt) > 0;
 }
 
+// camera.get_ray (camera.py:307-350) for any camera: the reference's float64 lens products (rf_general.h general_ray with the
+// per-environment constants the host prepared: GeneralCamera::u64 ...)
+template <class Cam>
+RF_HD void general_ray_any(const Cam &cam, float p0, float p1, float s, float t, float o[3], float d[3])
+{
+    const double rd0 = (double)p0 * cam.lens_radius, rd1 = (double)p1 * cam.lens_radius;
+RF_UNROLL
+    for (int k = 0; k < 3; ++k) {
+        o[k] = (cam.origin0[k] + (float)(cam.u64[k] * rd0)) + (float)(cam.v64[k] * rd1);
+        d[k] = ((cam.lower_left0[k] + cam.f[3 + k] * s) + cam.f[6 + k] * t) - o[k];
+    }
+}
+
 // camera.get_ray (camera.py:307-350) for a camera with simple axes and a lens radius whose float32 form is exact
 // (lens = {hi, lo} of rf_math.h lens_offset<1>); cf = GeneralCamera::f, origin0 / lower_left0 its leading sums
 template <class Cam>
@@ -312,16 +327,19 @@ RF_UNROLL
     }
 }
 
-// world.hit (world.py:126-167) over NS shapes + the checker colour of the closest hit; kDoubt poisons the sample
+// world.hit (world.py:126-167) over the environment's n_shapes <= NS shapes + the checker colour of the closest hit; kDoubt
+// poisons the sample
 template <int NS, class Shapes>
-RF_HD int world_hit_dense(const Shapes *sc, const float o[3], const float d[3], float t_min, float t_max, HitRec &rec,
-                          bool &doubt)
+RF_HD int world_hit_dense(const Shapes *sc, int n_shapes, const float o[3], const float d[3], float t_min, float t_max,
+                          HitRec &rec, bool &doubt)
 {
     const float a = dot3(d, d);
     float closest = t_max;
     int any = kMiss;
 RF_UNROLL
     for (int i = 0; i < NS; ++i) {
+        if (i >= n_shapes) // per environment: uniform
+            break;
         if (sc[i].type == 0) { // per environment: uniform
             const float centre[3] = {sc[i].p[0], sc[i].p[1], sc[i].p[2]};
             HitRec tmp;
@@ -350,10 +368,9 @@ RF_UNROLL
 }
 
 // one pixel of device_render (render.py:31-85); false: the pixel abstains (g, cr, cg, cb are then meaningless)
-template <bool POW2, int NS, class Cam, class Shapes>
-RF_HD bool render_pixel_dense(Rng &g, int x, int y, int spp, const Cam &cam, float lens_hi, float lens_lo,
-                              const Shapes *sc, const FrameConst &fc,
-                              float &cr, float &cg, float &cb)
+template <bool POW2, int NS, bool SIMPLE, class Cam, class Shapes>
+RF_HD bool render_pixel_dense(Rng &g, int x, int y, int spp, const Cam &cam, const Shapes *sc, int n_shapes,
+                              const FrameConst &fc, float &cr, float &cg, float &cb)
 {
     cr = cg = cb = 0.0f;
     bool doubt = false;
@@ -364,12 +381,15 @@ RF_HD bool render_pixel_dense(Rng &g, int x, int y, int spp, const Cam &cam, flo
         float p0, p1;
         disc_sample(g, p0, p1);
         float o[3], d[3];
-        general_ray_simple(cam, lens_hi, lens_lo, p0, p1, s, t, o, d);
+        if (SIMPLE)
+            general_ray_simple(cam, cam.lens_hi, cam.lens_lo, p0, p1, s, t, o, d);
+        else
+            general_ray_any(cam, p0, p1, s, t, o, d);
         float ar = 1.0f, ag = 1.0f, ab = 1.0f;
         bool black = false;
         for (int bounce = 0;;) { // physics.py:95-145 find_colour
             HitRec rec;
-            const int hit = world_hit_dense<NS>(sc, o, d, 0.001f, 1000000.0f, rec, doubt);
+            const int hit = world_hit_dense<NS>(sc, n_shapes, o, d, 0.001f, 1000000.0f, rec, doubt);
             if (hit == kDoubt)
                 doubt = true;
             if (hit != kHit)

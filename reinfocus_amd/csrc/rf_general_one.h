@@ -484,7 +484,8 @@ constexpr int kDenseOcc = 7; // waves per SIMD the register allocator is held to
 // hit-only code for a few lanes: 12 % fewer instructions on two-sphere scenes (lane utilisation 0.56 -> 0.64), and
 // row-major waves of a frame whose width is not a multiple of 64 straddle rows: +17 % at 300 px.  (16 x 4 pixel waves
 // are as fast, 32 x 2 ones 1 ... 6 % slower: profiles/r05_ab.txt section 3.)
-template <bool POW2, int NS, bool TILED>
+// SIMPLE: every camera of the launch has canonical axes and a lens radius whose float32 offset is exact (rf_general_dense.h)
+template <bool POW2, int NS, bool TILED, bool SIMPLE>
 __global__ __launch_bounds__(kBlock, kDenseOcc) void render_general_dense_kernel(GeneralOneArgs ra)
 {
     __shared__ uint32_t stage[kBlock * 3 / 4];
@@ -521,8 +522,9 @@ __global__ __launch_bounds__(kBlock, kDenseOcc) void render_general_dense_kernel
         Rng g = rng_load(st.x, st.y);
         const_as<GeneralCamera> &cam = *as_const(a.cameras + e);
         const_as<ShapeConst> *const sc = as_const(ra.shapes + (size_t)e * NS);
+        const int n_shapes = as_const(a.sizes)[e];
         float cr, cg, cb;
-        const bool keep = render_pixel_dense<POW2, NS>(g, x, y, a.spp, cam, cam.lens_hi, cam.lens_lo, sc, ra.fc, cr, cg, cb);
+        const bool keep = render_pixel_dense<POW2, NS, SIMPLE>(g, x, y, a.spp, cam, sc, n_shapes, ra.fc, cr, cg, cb);
         if (keep) {
             a.states[pix] = make_ulonglong2(rng_s0(g), rng_s1(g));
             r8 = (uint8_t)(cr * a.scale);

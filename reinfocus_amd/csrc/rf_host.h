@@ -48,9 +48,7 @@ struct rf_ctx {
     bool auto_form = true; // launches of few blocks take the kernel without cooperative tails (few_blocks;
                            // REINFOCUS_RENDER_SETS=3: three pixels per thread with them at every size)
     bool strip = true; // a frame's last w % 64 <= 48 columns as tiles of 48 x 16 (REINFOCUS_RENDER_STRIP=0: one tile shape)
-    int tile_layout = -1; // REINFOCUS_TILE_LAYOUT=0..5 forces one (experiments), -1: pick_tile_layout
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
-    bool focus_quad = true; // 4-pixels-per-thread focus kernel (REINFOCUS_FOCUS_QUAD=0 disables)
     bool general_one = true; // general renderer: cooperative kernel for one-shape worlds (REINFOCUS_GENERAL_ONE=0: never)
     bool general_one_always = false; // ... for launches of every size (REINFOCUS_GENERAL_ONE=1; default: large launches only)
     bool general_dense = true; // general renderer: the float32 kernel with abstentions for worlds of several shapes

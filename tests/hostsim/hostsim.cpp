@@ -456,27 +456,27 @@ long hs_check_sphere_hit_dense(const float *spheres, const float *origins, const
 }
 
 // rf_general_dense.h render_pixel_dense on the host: frames / states of the pixels that do not abstain, and which did
-// (abstained[pix] = 1: frame bytes and state untouched).  NS = most in {1, 2}; cameras must be simple (returns -1 if not).
+// (abstained[pix] = 1: frame bytes and state untouched).  NS = most in {1, 2, 3}, any counts up to it; cameras with canonical axes
+// take the SIMPLE instance unless `simple` is 0 (the float32 lens offset is then assumed exact for their radii: the reference's
+// default aperture), the others the float64 lens products.
 int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const double *cameras, const float *params,
                             const int32_t *types, const int32_t *sizes, int most, int width, uint64_t *states,
-                            uint8_t *abstained, unsigned perturb)
+                            uint8_t *abstained, unsigned perturb, int simple)
 {
     const float scale = (float)(255.0 / (double)spp);
     const bool pow2 = h > 0 && w > 0 && (h & (h - 1)) == 0 && (w & (w - 1)) == 0;
-    if (most < 1 || most > 2 || h > 4096 || w > 4096)
+    if (most < 1 || most > 3 || h > 4096 || w > 4096)
         return -1;
     const FrameConst fc = frame_const(h, w);
+    for (int e = 0; e < n; ++e)
+        simple = simple && camera_axes_simple(general_camera(cameras + (long)e * 19));
     for (int e = 0; e < n; ++e) {
-        if (sizes[e] != most)
+        if (sizes[e] < 0 || sizes[e] > most)
             return -1;
         const GeneralCamera cam = general_camera(cameras + (long)e * 19);
-        CamStatic cs{0, 0, 0, 0, 0, 0, 0, 0, 0, cam.lens_radius, cam.lens_hi, cam.lens_lo, 0};
-        if (!camera_axes_simple(cam))
-            return -1;
-        // (the exhaustive check of the radius: rf_abi_ctx.hip lens_split; here on the fly for the coordinates that occur)
-        ShapeConst sc[2];
+        ShapeConst sc[3];
         for (int i = 0; i < most; ++i)
-            sc[i] = shape_const(params + ((long)e * most + i) * width, width, types[(long)e * most + i]);
+            sc[i] = shape_const(params + ((long)e * most + i) * width, width, i < sizes[e] ? types[(long)e * most + i] : 1);
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
                 const long pix = ((long)e * h + y) * w + x;
@@ -484,11 +484,13 @@ int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const
                 float cr, cg, cb;
                 rf::g_dense_perturb = perturb ? (perturb + (unsigned)pix * 2654435761u) | 1u : 0u;
                 bool keep;
-#define HS_DENSE(P, N) keep = render_pixel_dense<P, N>(g, x, y, spp, cam, cam.lens_hi, cam.lens_lo, sc, fc, cr, cg, cb)
-                if (pow2 && most == 1) HS_DENSE(true, 1);
-                else if (pow2) HS_DENSE(true, 2);
-                else if (most == 1) HS_DENSE(false, 1);
-                else HS_DENSE(false, 2);
+#define HS_DENSE(P, N, S) keep = render_pixel_dense<P, N, S>(g, x, y, spp, cam, sc, sizes[e], fc, cr, cg, cb)
+#define HS_DENSE_N(P, S) do { if (most == 1) HS_DENSE(P, 1, S); else if (most == 2) HS_DENSE(P, 2, S); else HS_DENSE(P, 3, S); } while (0)
+                if (pow2 && simple) HS_DENSE_N(true, true);
+                else if (pow2) HS_DENSE_N(true, false);
+                else if (simple) HS_DENSE_N(false, true);
+                else HS_DENSE_N(false, false);
+#undef HS_DENSE_N
 #undef HS_DENSE
                 abstained[pix] = keep ? 0 : 1;
                 if (!keep)
@@ -499,7 +501,6 @@ int hs_render_general_dense(uint8_t *frames, int n, int h, int w, int spp, const
                 frames[pix * 3 + 1] = (uint8_t)(cg * scale);
                 frames[pix * 3 + 2] = (uint8_t)(cb * scale);
             }
-        (void)cs;
     }
     rf::g_dense_perturb = 0;
     return 0;

@@ -430,25 +430,35 @@ def test_double_float_sphere_roots_decide_like_the_float64_ones():
 
 @pytest.mark.parametrize("label,n,h,w,spp", [("two_sphere", 3, 64, 64, 16), ("mixed", 3, 64, 64, 16), ("two_rect", 2, 48, 80, 8),
                                              ("mixed", 2, 50, 70, 60), ("random2", 6, 40, 56, 8), ("random1", 6, 32, 32, 8),
-                                             ("random2", 3, 64, 32, 20)])
+                                             ("random2", 3, 64, 32, 20), ("random3", 5, 48, 48, 8), ("ragged", 8, 40, 56, 8),
+                                             ("ragged", 6, 32, 64, 12)])
 def test_dense_kernel_arithmetic_equals_oracle_wherever_it_does_not_abstain(oracle, label, n, h, w, spp):
-    """rf_general_dense.h render_pixel_dense compiled for the host on the reference's two-shape factories and on random
-    worlds of one and two shapes: every pixel that does not abstain has the oracle's bytes and final RNG state (also
-    with the 1-ulp approximations nudged), the pixels that abstain are left untouched, and they are few."""
+    """rf_general_dense.h render_pixel_dense compiled for the host on the reference's two-shape factories, on random
+    worlds of one, two and three shapes under cameras with canonical axes (the float32 lens offset, and the float64 lens
+    products on the same scenes) and on ragged worlds under tilted cameras with apertures of every size (_random_scene):
+    every pixel that does not abstain has the oracle's bytes and final RNG state (also with the 1-ulp approximations
+    nudged), the pixels that abstain are left untouched, and they are few."""
     hs = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
     p = ctypes.c_void_p
-    hs.hs_render_general_dense.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p, p, ctypes.c_uint]
+    hs.hs_render_general_dense.argtypes = [p] + [ctypes.c_int] * 4 + [p, p, p, p, ctypes.c_int, ctypes.c_int, p, p, ctypes.c_uint,
+                                           ctypes.c_int]
     rng = np.random.default_rng(n * 100 + h)
-    cameras, (params, types, sizes) = (_few_shape_worlds(rng, n, int(label[-1])) if label.startswith("random")
-                                       else _factory_worlds(rng, n, label))
+    if label == "ragged":
+        cameras, (params, types, sizes) = _random_scene(rng, n)
+        cameras, params, types, sizes = (np.ascontiguousarray(a) for a in (cameras, params, types, sizes))
+        if params.shape[2] < 7:
+            params = np.ascontiguousarray(np.pad(params, ((0, 0), (0, 0), (0, 7 - params.shape[2]))))
+    else:
+        cameras, (params, types, sizes) = (_few_shape_worlds(rng, n, int(label[-1])) if label.startswith("random")
+                                           else _factory_worlds(rng, n, label))
     st0 = oracle.seed_states(n * h * w, 0)
     st = st0.copy()
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=8)
-    for perturb in (0, 99):
+    for perturb, simple in ((0, 1), (99, 1), (0, 0)):
         got, s2, gave_up = np.zeros_like(want), st0.copy(), np.zeros(n * h * w, dtype=np.uint8)
         rc = hs.hs_render_general_dense(got.ctypes.data, n, h, w, spp, cameras.ctypes.data, params.ctypes.data, types.ctypes.data,
                                         sizes.ctypes.data, params.shape[1], params.shape[2], s2.ctypes.data, gave_up.ctypes.data,
-                                        perturb)
+                                        perturb, simple)
         assert rc == 0
         keep = gave_up.reshape(n, h, w) == 0
         assert np.array_equal(got[keep], want[keep])

@@ -45,7 +45,11 @@ def test_general_golden(ctx_choice, golden_dir, name):
 
 @pytest.mark.parametrize("n,h,w,spp,seed", [(8, 40, 56, 6, 1), (3, 96, 64, 8, 2), (16, 33, 35, 3, 3), (12, 64, 64, 12, 4),
                                            (6, 50, 128, 5, 5), (2, 256, 256, 4, 6)])
-def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, seed):
+def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, seed, monkeypatch):
+    """Ragged worlds of one to three shapes under tilted cameras with apertures of every size: the dense kernel's instances
+    with float64 lens products -- and the literal kernel (REINFOCUS_GENERAL_DENSE=0) on the same scenes."""
+    from reinfocus_amd import _native
+
     ctx = ctx_choice
     rng = np.random.default_rng(seed)
     cameras, (params, types, sizes) = _random_scene(rng, n)
@@ -58,6 +62,15 @@ def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, se
     differing = np.any(got != want, axis=-1).sum()
     assert differing == 0, f"{differing} of {n * h * w} pixels differ"
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
+    assert ctx.render_kernel_name().startswith("render_general_dense_kernel") and ctx.render_kernel_name().endswith(", false>")
+    monkeypatch.setenv("REINFOCUS_GENERAL_DENSE", "0")
+    literal = _native.Context(0)
+    try:
+        assert np.array_equal(literal.render_general(cameras, params, types, sizes, h, w, spp), want)
+        assert np.array_equal(literal.get_states(0, n * h * w), st)
+        assert literal.render_kernel_name().startswith("render_general_kernel")
+    finally:
+        literal.close()
 
 
 def test_general_renderer_reseeds_for_every_call(ctx, oracle):
@@ -205,10 +218,11 @@ def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, 
 
 @pytest.mark.parametrize("kind,n,h,w,spp,cooperative", [("rectangle", 2, 300, 600, 3, False), ("rectangle", 36, 256, 256, 2, True),
                                                        ("sphere", 36, 256, 256, 2, False), ("sphere", 50, 256, 256, 2, True)])
-def test_small_one_shape_launches_take_the_literal_kernel(oracle, tmp_path, kind, n, h, w, spp, cooperative):
+def test_small_one_shape_launches_take_a_kernel_without_barriers(oracle, tmp_path, kind, n, h, w, spp, cooperative):
     """Without REINFOCUS_GENERAL_ONE the library takes the cooperative single-shape kernel only for launches that fill the
     device (more than 2 M pixels with a rectangle, 3 M with a sphere): the notebooks' one or two environments are bound by
-    the latency of a sample, and the literal kernel is up to three times faster there.  Same frames and states either way."""
+    the latency of a sample, and a kernel without barriers -- the dense one -- is up to three times faster there.  Same
+    frames and states either way."""
     import subprocess
     import sys
 
@@ -229,15 +243,15 @@ def test_small_one_shape_launches_take_the_literal_kernel(oracle, tmp_path, kind
     automatic = {k: v for k, v in os.environ.items() if k != "REINFOCUS_GENERAL_ONE"}
     subprocess.check_call([sys.executable, "-c", script], env=automatic)
     got = np.load(out)
-    assert str(got["kernel"]).startswith("render_general_one_kernel" if cooperative else "render_general_kernel"), got["kernel"]
+    assert str(got["kernel"]).startswith("render_general_one_kernel" if cooperative else "render_general_dense_kernel"), got["kernel"]
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     assert np.array_equal(got["frames"], want) and np.array_equal(got["states"], st)
 
 
-def test_one_shape_worlds_of_both_kinds_take_the_literal_kernel(ctx, oracle):
+def test_one_shape_worlds_of_both_kinds_do_not_take_the_cooperative_kernel(ctx, oracle):
     """The cooperative kernel is compiled for one kind of shape per launch: a batch whose environments hold one
-    rectangle here and one sphere there is rendered by the literal kernel (and equals the oracle as any batch does)."""
+    rectangle here and one sphere there is rendered by the dense kernel (and equals the oracle as any batch does)."""
     rng = np.random.default_rng(31)
     cam_r, (par_r, typ_r, siz_r) = _random_one_shape_worlds(rng, 2, "rectangle")
     cam_s, (par_s, typ_s, siz_s) = _random_one_shape_worlds(rng, 3, "sphere")
@@ -249,7 +263,7 @@ def test_one_shape_worlds_of_both_kinds_take_the_literal_kernel(ctx, oracle):
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
-    assert ctx.render_kernel_name().startswith("render_general_kernel")
+    assert not ctx.render_kernel_name().startswith("render_general_one_kernel")
     assert np.array_equal(got, want) and np.array_equal(ctx.get_states(0, n * h * w), st)
 
 
@@ -321,9 +335,9 @@ def _general_in_child(tmp_path, scene, h, w, spp, env):
                                              ("mixed", 2, 300, 300, 12), ("random2", 8, 40, 56, 8), ("random1", 6, 32, 32, 8),
                                              ("random2", 5, 33, 35, 6), ("random2", 3, 256, 256, 5), ("random1", 3, 100, 164, 7),
                                              ("two_sphere", 2, 60, 100, 100), ("random2", 4, 64, 8, 5), ("random2", 6, 7, 90, 4),
-                                             ("mixed", 3, 12, 256, 6)])
+                                             ("mixed", 3, 12, 256, 6), ("random3", 5, 48, 64, 7), ("random3", 3, 100, 100, 5)])
 def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle, monkeypatch, label, n, h, w, spp):
-    """Worlds of one or two shapes in every environment, seen by cameras with canonical axes through an aperture whose
+    """Worlds of one, two or three shapes in every environment, seen by cameras with canonical axes through an aperture whose
     float32 lens offset is exact, are rendered by render_general_dense_kernel (rf_general_dense.h: no float64, the
     sphere's roots in double-float, pixel-level abstention) + the fix-up kernel: frames and final RNG states
     bit-identical to the oracle's -- power-of-two and other frames, widths that are not multiples of four (byte stores),
@@ -347,7 +361,7 @@ def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle
             assert c.render_kernel_name().startswith(kernel), c.render_kernel_name()
             if c is dense:  # 16 x 16 tiles unless they pad the frame more than 15 % beyond what 256-pixel runs do
                 tiled = -(-w // 16) * -(-h // 16) * 100 <= -(-h * w // 256) * 115
-                assert c.render_kernel_name().endswith(", true>" if tiled else ", false>"), c.render_kernel_name()
+                assert c.render_kernel_name().endswith(", true, true>" if tiled else ", false, true>"), c.render_kernel_name()
             differing = np.any(got != want, axis=-1).sum()
             assert differing == 0, f"{kernel}: {differing} of {n * h * w} pixels differ"
             assert np.array_equal(c.get_states(0, n * h * w), st), kernel
@@ -357,33 +371,36 @@ def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle
         literal.close()
 
 
-def test_worlds_the_dense_kernel_does_not_take(ctx, oracle):
-    """Cameras that look from the side (axes with components other than 0 and +-1), apertures whose float32 lens offset
-    is not exact, worlds of three shapes or of different counts: the literal kernel, as before."""
+def test_which_worlds_take_which_dense_instance(ctx, oracle):
+    """Up to three shapes per environment, any counts: the dense kernel -- its SIMPLE instances (float32 lens offset) when
+    every camera has canonical axes and a lens radius whose float32 offset rf_abi_ctx.hip lens_split finds exact, the
+    instances with the reference's float64 lens products for tilted cameras and other radii; four shapes: the literal
+    kernel.  The oracle's frames either way."""
     from reinfocus_amd.graphics import camera, shape_factory as sf, world
 
     two = sf.two_sphere(sf.ShapeParameters(12.0), sf.ShapeParameters(6.0))
-    side = camera.Cameras(camera.make_gpu_camera(look_from=(1.0, 0.5, 0.0)), camera.make_gpu_camera())
     p, t, s = world.Worlds(two, two).device_data()
-    ctx.render_general(side.device_data(), p, t, s, 32, 32, 2)
-    assert ctx.render_kernel_name().startswith("render_general_kernel")
+
+    def check(cams, params, types, sizes, kernel, suffix=""):
+        st = oracle.seed_states(len(sizes) * 24 * 24, 0)
+        want = oracle.render_general(cams.device_data(), params, types, sizes, 24, 24, 3, st, n_threads=4)
+        assert np.array_equal(ctx.render_general(cams.device_data(), params, types, sizes, 24, 24, 3), want)
+        assert np.array_equal(ctx.get_states(0, len(sizes) * 24 * 24), st)
+        name = ctx.render_kernel_name()
+        assert name.startswith(kernel) and name.endswith(suffix), name
+
     straight = camera.Cameras(camera.make_gpu_camera(), camera.make_gpu_camera())
-    ctx.render_general(straight.device_data(), p, t, s, 32, 32, 2)
-    assert ctx.render_kernel_name().startswith("render_general_dense_kernel")
-    p3, t3, s3 = world.Worlds(two + sf.one_rect(), two + sf.one_rect()).device_data()
-    ctx.render_general(straight.device_data(), p3, t3, s3, 32, 32, 2)
-    assert ctx.render_kernel_name().startswith("render_general_kernel")
-    pr, tr, sr = world.Worlds(two, sf.one_sphere()).device_data()
-    ctx.render_general(straight.device_data(), pr, tr, sr, 32, 32, 2)
-    assert ctx.render_kernel_name().startswith("render_general_kernel")
-    # apertures for which rf_abi_ctx.hip lens_split finds disc coordinates whose float32 offset differs from the float64
-    # one (the radii of tests/test_gpu_parity.py::test_lens_radius_forms), and two for which it finds none
-    for aperture, dense in ((2 * 0.6243510725689605, False), (2 * 0.46456785704581477, False), (0.14, True), (0.125, True)):
+    side = camera.Cameras(camera.make_gpu_camera(look_from=(1.0, 0.5, 0.0)), camera.make_gpu_camera())
+    check(straight, p, t, s, "render_general_dense_kernel<false, 2", ", true>")
+    check(side, p, t, s, "render_general_dense_kernel<false, 2", ", false>")
+    check(straight, *world.Worlds(two + sf.one_rect(), two + sf.one_rect()).device_data(), "render_general_dense_kernel<false, 3", ", true>")
+    check(straight, *world.Worlds(two, sf.one_sphere()).device_data(), "render_general_dense_kernel<false, 2", ", true>")  # (ragged)
+    check(straight, *world.Worlds(two + two, two + two).device_data(), "render_general_kernel<false>")
+    # apertures for which lens_split finds disc coordinates whose float32 offset differs from the float64 one (the radii of
+    # tests/test_gpu_parity.py::test_lens_radius_forms), and two for which it finds none
+    for aperture, simple in ((2 * 0.6243510725689605, False), (2 * 0.46456785704581477, False), (0.14, True), (0.125, True)):
         cams = camera.Cameras(camera.make_gpu_camera(aperture=aperture), camera.make_gpu_camera(aperture=aperture))
-        st = oracle.seed_states(2 * 24 * 24, 0)
-        want = oracle.render_general(cams.device_data(), p, t, s, 24, 24, 3, st, n_threads=4)
-        assert np.array_equal(ctx.render_general(cams.device_data(), p, t, s, 24, 24, 3), want), aperture
-        assert ctx.render_kernel_name().startswith("render_general_dense_kernel" if dense else "render_general_kernel"), aperture
+        check(cams, p, t, s, "render_general_dense_kernel<false, 2", ", true>" if simple else ", false>")
 
 
 def test_a_fix_up_list_that_overflows_is_rendered_again_by_the_literal_kernel(oracle, tmp_path):
