@@ -194,7 +194,7 @@ int rf_create(int device, rf_ctx **out)
     if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
         ctx->auto_form = v[0] != '3'; // (3: three pixels per thread with cooperative tails for launches of every size)
     if (const char *v = getenv("REINFOCUS_GENERAL_DENSE"))
-        ctx->general_dense = v[0] != '0';
+        ctx->general_dense = v[0] != '0', ctx->general_dense_always = v[0] == '1';
     if (const char *v = getenv("REINFOCUS_ENV_FUSED"))
         ctx->env_fused = strcmp(v, "0") != 0;
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH"))

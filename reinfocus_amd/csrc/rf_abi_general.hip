@@ -82,10 +82,14 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     //    (more than 2 M pixels with a rectangle, 3 M with a sphere): the cooperative kernel of rf_general_one.h.  The
     //    notebooks' one or two environments are a few hundred blocks, bound by the latency of a sample, where a kernel
     //    without barriers is up to three times faster (profiles/r04_ab.txt section 19).
-    //  * kDense: at most three shapes per environment, frames the quick pixel coordinates are proven for: the float32 kernel
-    //    with abstentions (rf_general_dense.h) -- its SIMPLE instances when every camera has canonical axes and a lens radius
-    //    whose float32 offset is exact, the ones with the reference's float64 lens products otherwise.
-    //  * kLiteral: everything else (more shapes, frames beyond 4096 pixels).
+    //  * kDense: at most three shapes per environment, frames the quick pixel coordinates are proven for, launches of more
+    //    than 2 M pixels: the float32 kernel with abstentions (rf_general_dense.h) -- its SIMPLE instances when every camera
+    //    has canonical axes and a lens radius whose float32 offset is exact, the ones with the reference's float64 lens
+    //    products otherwise.  Its fix-up kernel renders the pixels that abstained one thread each, which takes as long as
+    //    the literal kernel takes for a launch that does not fill the device: below 2 M pixels the literal kernel is up to
+    //    twice as fast (1 x 300 x 600 x 100: 0.52 against 1.03 ms; 32 x 256^2 x 16: 0.63 against 0.61: profiles/r05_ab.txt
+    //    section 8).
+    //  * kLiteral: everything else (more shapes, frames beyond 4096 pixels, small launches).
     enum { kLiteral, kOne, kDense } kind = kLiteral;
     const bool quick_frame = h <= 4096 && w <= 4096;
     bool uniform_count = true;
@@ -99,7 +103,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
         one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
     if (one_shape) {
         kind = kOne;
-    } else if (ctx->general_dense && quick_frame && most <= 3) {
+    } else if (ctx->general_dense && quick_frame && most <= 3 && (ctx->general_dense_always || pixels > 2000000u)) {
         kind = kDense;
         simple_cameras = true;
         for (int e = 0; simple_cameras && e < n; ++e) {

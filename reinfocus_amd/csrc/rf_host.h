@@ -51,8 +51,9 @@ struct rf_ctx {
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool general_one = true; // general renderer: cooperative kernel for one-shape worlds (REINFOCUS_GENERAL_ONE=0: never)
     bool general_one_always = false; // ... for launches of every size (REINFOCUS_GENERAL_ONE=1; default: large launches only)
-    bool general_dense = true; // general renderer: the float32 kernel with abstentions for worlds of several shapes
-                               // (REINFOCUS_GENERAL_DENSE=0: the literal kernel)
+    bool general_dense = true; // general renderer: the float32 kernel with abstentions for worlds of up to three shapes
+                               // (REINFOCUS_GENERAL_DENSE=0: never)
+    bool general_dense_always = false; // ... for launches of every size (REINFOCUS_GENERAL_DENSE=1; default: large launches only)
 
     uint8_t *d_frames = nullptr;
     size_t frames_cap = 0;

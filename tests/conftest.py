@@ -19,6 +19,8 @@ def pytest_configure(config):
     # device; the tests render it at every size (test_gpu_general.py::test_small_one_shape_launches_take_the_literal_kernel
     # runs the library's choice)
     os.environ.setdefault("REINFOCUS_GENERAL_ONE", "1")
+    # and its dense kernel for worlds of up to three shapes (the library: launches of more than 2 M pixels)
+    os.environ.setdefault("REINFOCUS_GENERAL_DENSE", "1")
 
 
 def pytest_sessionstart(session):
@@ -68,6 +70,7 @@ def kernel_choice(request, monkeypatch):
     if request.param == "the library's choice":
         monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
         monkeypatch.delenv("REINFOCUS_GENERAL_ONE", raising=False)
+        monkeypatch.delenv("REINFOCUS_GENERAL_DENSE", raising=False)
     return request.param
 
 

@@ -45,7 +45,7 @@ def test_general_golden(ctx_choice, golden_dir, name):
 
 @pytest.mark.parametrize("n,h,w,spp,seed", [(8, 40, 56, 6, 1), (3, 96, 64, 8, 2), (16, 33, 35, 3, 3), (12, 64, 64, 12, 4),
                                            (6, 50, 128, 5, 5), (2, 256, 256, 4, 6)])
-def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, seed, monkeypatch):
+def test_general_random_scenes_match_oracle(ctx_choice, kernel_choice, oracle, n, h, w, spp, seed, monkeypatch):
     """Ragged worlds of one to three shapes under tilted cameras with apertures of every size: the dense kernel's instances
     with float64 lens products -- and the literal kernel (REINFOCUS_GENERAL_DENSE=0) on the same scenes."""
     from reinfocus_amd import _native
@@ -62,6 +62,9 @@ def test_general_random_scenes_match_oracle(ctx_choice, oracle, n, h, w, spp, se
     differing = np.any(got != want, axis=-1).sum()
     assert differing == 0, f"{differing} of {n * h * w} pixels differ"
     assert np.array_equal(ctx.get_states(0, n * h * w), st)
+    if kernel_choice == "the library's choice":  # (launches of this size: the literal kernel)
+        assert ctx.render_kernel_name().startswith("render_general_kernel")
+        return
     assert ctx.render_kernel_name().startswith("render_general_dense_kernel") and ctx.render_kernel_name().endswith(", false>")
     monkeypatch.setenv("REINFOCUS_GENERAL_DENSE", "0")
     literal = _native.Context(0)
@@ -218,11 +221,11 @@ def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, 
 
 @pytest.mark.parametrize("kind,n,h,w,spp,cooperative", [("rectangle", 2, 300, 600, 3, False), ("rectangle", 36, 256, 256, 2, True),
                                                        ("sphere", 36, 256, 256, 2, False), ("sphere", 50, 256, 256, 2, True)])
-def test_small_one_shape_launches_take_a_kernel_without_barriers(oracle, tmp_path, kind, n, h, w, spp, cooperative):
-    """Without REINFOCUS_GENERAL_ONE the library takes the cooperative single-shape kernel only for launches that fill the
-    device (more than 2 M pixels with a rectangle, 3 M with a sphere): the notebooks' one or two environments are bound by
-    the latency of a sample, and a kernel without barriers -- the dense one -- is up to three times faster there.  Same
-    frames and states either way."""
+def test_small_launches_take_the_literal_kernel(oracle, tmp_path, kind, n, h, w, spp, cooperative):
+    """Without REINFOCUS_GENERAL_ONE / _DENSE the library takes the cooperative single-shape kernel and the dense kernel
+    only for launches that fill the device (more than 2 M pixels; 3 M for a lone sphere): the notebooks' one or two
+    environments are bound by the latency of a pixel's samples, where the literal kernel -- no barriers, no second kernel
+    for the pixels that abstained -- is two to three times faster.  Same frames and states either way."""
     import subprocess
     import sys
 
@@ -240,10 +243,12 @@ def test_small_one_shape_launches_take_a_kernel_without_barriers(oracle, tmp_pat
         "np.savez(%r, frames=f, states=c.get_states(0, %d), kernel=c.render_kernel_name())\n"
         "c.close()\n"
     ) % (helpers.ROOT, str(tmp_path / "scene.npz"), h, w, spp, str(out), n * h * w)
-    automatic = {k: v for k, v in os.environ.items() if k != "REINFOCUS_GENERAL_ONE"}
+    automatic = {k: v for k, v in os.environ.items() if k not in ("REINFOCUS_GENERAL_ONE", "REINFOCUS_GENERAL_DENSE")}
     subprocess.check_call([sys.executable, "-c", script], env=automatic)
     got = np.load(out)
-    assert str(got["kernel"]).startswith("render_general_one_kernel" if cooperative else "render_general_dense_kernel"), got["kernel"]
+    # (36 spheres of 256^2: 2.4 M pixels -- not enough for the cooperative kernel, enough for the dense one)
+    other = "render_general_dense_kernel" if n * h * w > 2_000_000 else "render_general_kernel"
+    assert str(got["kernel"]).startswith("render_general_one_kernel" if cooperative else other), got["kernel"]
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     assert np.array_equal(got["frames"], want) and np.array_equal(got["states"], st)
@@ -352,6 +357,7 @@ def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     monkeypatch.setenv("REINFOCUS_GENERAL_ONE", "0")  # (one-shape worlds: not the cooperative kernel of rf_general_one.h)
+    monkeypatch.setenv("REINFOCUS_GENERAL_DENSE", "1")
     dense = _native.Context(0)
     monkeypatch.setenv("REINFOCUS_GENERAL_DENSE", "0")
     literal = _native.Context(0)
