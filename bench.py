@@ -136,6 +136,10 @@ def launch_ranks(world, argv, total_timeout=None):
             env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # as torch.distributed.run does: N ranks with an OpenMP team of every core each (torch's, behind the per-step gloo
+            # gather) starve each other and the HIP runtime's threads -- 60 instead of 25.5 ms per rank and step in a 6-rank
+            # rehearsal (profiles/r05_ab.txt section 9)
+            env.setdefault("OMP_NUM_THREADS", "1")
             out = subprocess.PIPE if rank == 0 else sys.stderr
             children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                              stdout=out, cwd=os.getcwd()))

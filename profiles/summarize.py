@@ -122,7 +122,7 @@ def main(tag):
     # listing `make -C reinfocus_amd/csrc asm` writes), with the per-class costs measured by tools/ubench/pairbench
     kernel = (meta["config"] or {}).get("kernel") or ""
     match = __import__("re").match(r"render_kernel_coop2<(true|false), (\d+), (\d+), (\d+)(, true|, false)?>", kernel)
-    listing = os.path.join(root, "..", "reinfocus_amd", "csrc", "rf_abi.gfx950.s")
+    listing = os.path.join(root, "..", "reinfocus_amd", "csrc", "rf_abi_render.gfx950.s")  # (the render kernels' unit)
     strip = __import__("re").match(r"render_kernel_coop2_strip<(\d+), (\d+)>", kernel)
     if (match or strip) and os.path.exists(listing):
         sys.path.insert(0, os.path.join(root, "..", "tools"))
