@@ -211,8 +211,9 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             d.redo_cap = (unsigned)cap;
             d.shapes = (const rf::ShapeConst *)(scratch + o_shp) + (size_t)e0 * most;
             d.fc = rf::frame_const(h, w);
-            const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kBlock - 1) / rf::kBlock;
-            const dim3 fix((unsigned)std::min<uint64_t>(blocks, 2048));
+            // (the fix-up kernel: kFixupLanes pixels per wave, grid-stride; 4096 blocks hold 16 K waves)
+            const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kFixupLanes * 4 - 1) / (rf::kFixupLanes * 4);
+            const dim3 fix((unsigned)std::min<uint64_t>(blocks, 4096));
             if (kind == kDense) {
                 // 16 x 16 tiles (waves of 8 x 8 pixels) unless they pad the frame much more than 256-pixel runs do (frames
                 // narrower or lower than a tile)

@@ -449,13 +449,22 @@ render_general_one_kernel(GeneralOneArgs ra)
 
 // The listed pixels, literally (rf_general.h render_pixel_general: float64 sines where float32 cannot decide, any
 // number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it
-// reads itself.
+// reads itself.  The list is short (a launch's pixels / 10^3) and the kernel's duration is the latency of ONE pixel's
+// samples, most of it the in-wave rejection loops' max-over-lanes trips: kFixupLanes pixels per wave instead of 64 shorten
+// those (RF_FIXUP_LANES 64 / 32 / 16 / 8: profiles/r05_ab.txt section 10), the registers are unbounded (no spills).
+#ifndef RF_FIXUP_LANES
+#define RF_FIXUP_LANES 32
+#endif
+constexpr unsigned kFixupLanes = RF_FIXUP_LANES;
 template <bool POW2>
 __global__ __launch_bounds__(kBlock) void render_general_fixup_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
     const unsigned total = min(*ra.redo_count, ra.redo_cap); // (more than the list holds: the host renders the launch again)
-    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    const unsigned lane = threadIdx.x & 63u, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, waves = gridDim.x * (kBlock / 64);
+    if (lane >= kFixupLanes)
+        return;
+    for (unsigned i = wave * kFixupLanes + lane; i < total; i += waves * kFixupLanes) {
         const unsigned pix = ra.redo_list[i];
         const int e = (int)(pix / (unsigned)a.hw), p = (int)(pix - (unsigned)e * (unsigned)a.hw);
         const int y = p / a.w, x = p - y * a.w;
