@@ -101,17 +101,22 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                      (ctx->general_one_always || pixels > (one_sphere ? 3000000u : 2000000u));
     for (int e = 0; one_shape && e < n; ++e)
         one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
-    if (one_shape) {
-        kind = kOne;
-    } else if (ctx->general_dense && quick_frame && most <= 3 && (ctx->general_dense_always || pixels > 2000000u)) {
-        kind = kDense;
-        simple_cameras = true;
-        for (int e = 0; simple_cameras && e < n; ++e) {
+    auto cameras_simple = [&]() {
+        for (int e = 0; e < n; ++e) {
             rf::CamStatic probe{};
             probe.lens_radius = cams[(size_t)e].lens_radius;
             lens_split(probe); // (remembered per radius)
-            simple_cameras = probe.lens_f32 != 0 && rf::camera_axes_simple(cams[(size_t)e]);
+            if (probe.lens_f32 == 0 || !rf::camera_axes_simple(cams[(size_t)e]))
+                return false;
         }
+        return true;
+    };
+    if (one_shape) {
+        kind = kOne;
+        simple_cameras = cameras_simple();
+    } else if (ctx->general_dense && quick_frame && most <= 3 && (ctx->general_dense_always || pixels > 2000000u)) {
+        kind = kDense;
+        simple_cameras = cameras_simple();
     }
     const bool listed = kind != kLiteral;
 
@@ -210,6 +215,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             d.redo_list = (unsigned *)(scratch + o_lst);
             d.redo_cap = (unsigned)cap;
             d.shapes = (const rf::ShapeConst *)(scratch + o_shp) + (size_t)e0 * most;
+            d.simple_cameras = simple_cameras ? 1 : 0;
             d.fc = rf::frame_const(h, w);
             // (the fix-up kernel: kFixupLanes pixels per wave, grid-stride; 4096 blocks hold 16 K waves)
             const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kFixupLanes * 4 - 1) / (rf::kFixupLanes * 4);

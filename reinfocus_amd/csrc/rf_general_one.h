@@ -45,6 +45,7 @@ struct GeneralOneArgs {
     unsigned redo_cap;    // entries the list holds; a launch that abstains more often is rendered again by the literal
                           // kernel from fresh states (rf_abi_general.hip)
     const ShapeConst *shapes; // [n][NS] (render_general_dense_kernel)
+    int simple_cameras;       // every camera of the launch: canonical axes, lens radius with an exact float32 offset
     FrameConst fc; // frame sizes in the forms the jittered coordinates use (rf_math.h)
 };
 
@@ -244,7 +245,12 @@ render_general_one_kernel(GeneralOneArgs ra)
             float p0, p1;
             disc_finish(w[j], p0, p1);
             float o[3], d[3];
-            general_ray_scalar(cam, p0, p1, s[j], t[j], o, d);
+            // (cameras with canonical axes and a lens radius whose float32 offset is exact -- all of the launch's, the host
+            // says: rf_general_dense.h -- need no float64 lens products: +3 % on one-rectangle scenes)
+            if (scalar_now(ra.simple_cameras))
+                general_ray_simple(cam, cam.lens_hi, cam.lens_lo, p0, p1, s[j], t[j], o, d);
+            else
+                general_ray_scalar(cam, p0, p1, s[j], t[j], o, d);
             red_m[j] = doubt_m[j] = 0;
             if (SPHERE) {
                 const float sp[4] = {centre[0], centre[1], centre[2], radius};
@@ -252,6 +258,8 @@ render_general_one_kernel(GeneralOneArgs ra)
                 rec.p[0] = rec.p[1] = rec.p[2] = 0.0f;
                 rec.n[0] = rec.n[1] = rec.n[2] = 0.0f;
                 bool hit = false, red = false, doubt = false;
+                // (the literal float64 roots: the dense kernel's double-float form is 2 % slower here -- this kernel's
+                // occupancy is set by its three pixel sets, not by the roots: profiles/r05_ab.txt section 11)
                 if (lane_in(live_m[j]))
                     hit = sphere_hit(sp, o, d, t_min, t_max, rec);
                 hit_m[j] = live_m[j] & lanes_where(hit);

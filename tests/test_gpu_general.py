@@ -197,16 +197,19 @@ def _random_one_shape_worlds(rng, n, kind="rectangle"):
     return camera.Cameras(*cams).device_data(), world.Worlds(*envs).device_data()
 
 
+@pytest.mark.parametrize("axes", ["tilted", "canonical"])
 @pytest.mark.parametrize("kind", ["rectangle", "sphere"])
 @pytest.mark.parametrize("n,h,w,spp,seed", [(5, 40, 56, 6, 1), (3, 96, 64, 8, 2), (7, 33, 35, 3, 3), (4, 128, 128, 9, 4),
                                            (2, 300, 300, 4, 5), (3, 16, 260, 5, 6), (2, 7, 500, 2, 7), (6, 64, 64, 20, 8)])
-def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, oracle, n, h, w, spp, seed, kind):
+def test_one_shape_worlds_take_the_cooperative_kernel_and_match_the_oracle(ctx, oracle, n, h, w, spp, seed, kind, axes):
     """Worlds of one rectangle per environment go through render_general_one_kernel (rf_general_one.h: the fast path's
     organisation with the general renderer's arithmetic) + the fix-up kernel: frames and final RNG states bit-identical to
     the oracle's general path for power-of-two and other frames, widths that are not multiples of four (byte stores),
-    partial tiles, frames wider than high, and switching back to the literal kernel gives the same."""
+    partial tiles, frames wider than high; cameras that look from off the axis through apertures of every size (float64
+    lens products) and cameras with canonical axes and the default aperture (the float32 lens offset)."""
     rng = np.random.default_rng(seed)
-    cameras, (params, types, sizes) = _random_one_shape_worlds(rng, n, kind)
+    cameras, (params, types, sizes) = (_random_one_shape_worlds(rng, n, kind) if axes == "tilted"
+                                       else _few_shape_worlds(rng, n, 1, kinds=kind))
     st = oracle.seed_states(n * h * w, 0)
     want = oracle.render_general(cameras, params, types, sizes, h, w, spp, st, n_threads=16)
     got = ctx.render_general(cameras, params, types, sizes, h, w, spp)
