@@ -326,7 +326,7 @@ RF_HD Colour find_colour(const float *params, const int32_t *types, int n_shapes
 
 // camera.from_cameras (camera.py:255-281): the float64[19] row of camera.Cameras cast to the
 // float32 tuples the kernel works with (lens radius stays float64).  The casts are per
-// environment, not per pixel: the GPU path does them once on the host (rf_abi.hip) so that the
+// environment, not per pixel: the GPU path does them once on the host (rf_abi_general.hip) so that the
 // kernel reads block-uniform floats into scalar registers.
 struct GeneralCamera {
     float f[18]; // lower_left, horizontal, vertical, origin, u, v

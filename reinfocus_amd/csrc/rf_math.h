@@ -188,7 +188,7 @@ struct CamStatic { // camera.py:39-52 FastGpuCameras minus the per-env array
 // fma(p, hi, RN32(p * lo)) carries a relative error below 2^-47 before its single rounding, so
 // it equals the doubly rounded reference unless p * lens_radius lies within 2^-47 of a float32
 // rounding boundary; whether that happens for any of the possible p is a property of the radius
-// alone, and the host checks all of them once per radius (rf_abi.hip lens_split; none for the
+// alone, and the host checks all of them once per radius (rf_abi_ctx.hip lens_split; none for the
 // reference's aperture 0.1).  Otherwise the literal float64 form is used.
 // LENS: 1 / 0 = the form is fixed at compile time (the caller has looked at cs.lens_f32),
 // -1 = decided at run time.

@@ -20,7 +20,7 @@ struct RenderArgs {
     int hw;          // h*w
     float scale;     // float32(255.0 / spp)   (render.py:244-246)
     FrameConst fc;   // frame sizes in the forms the jittered coordinates use (rf_math.h)
-    // render_kernel_coop2<..., TWO = true> (the environment step as one launch, rf_abi.hip enqueue_env_step_fused): the
+    // render_kernel_coop2<..., TWO = true> (the environment step as one launch, rf_abi_env.hip enqueue_env_step): the
     // blocks of the environments below *count2 render their tile twice -- the step's frame into frames2, then the scene
     // cam_dyn2 / rect2 of the same slot into frames, continuing the pixels' RNG streams (vector_environment.py:137-151:
     // the r-th environment that ended is rendered again as row r of a compacted set, render.py:217)

@@ -1,7 +1,7 @@
 """Launch-shape helpers with the reference's semantics (reinfocus/graphics/cutil.py:16-104).
 
 The gfx950 kernels fix their own launch geometry (256-thread blocks, one tile of one environment
-per block: see rf_abi.hip pick_tile_layout), so nothing here sizes a launch.  The functions exist
+per block: see rf_abi_render.hip pick_tile_layout), so nothing here sizes a launch.  The functions exist
 because `block_shape` is part of FastRenderer's and render()'s signatures: it is normalised with
 the reference's rules (limit_block_size) and checked, and `enough_blocks` answers the same
 questions the reference's callers and tests ask of it.

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The library renders launches of few blocks with its kernel without cooperative tails (rf_abi.hip few_blocks) --
+    # The library renders launches of few blocks with its kernel without cooperative tails (rf_abi_render.hip few_blocks) --
     # which is most of what tests render.  The tests are there for the benchmarked kernel: three pixels per thread at every size, unless a
     # test asks otherwise (tests/test_gpu_parity.py::test_few_blocks_take_one_pixel_per_thread and the notebook outputs
     # run the automatic choice).

@@ -102,7 +102,7 @@ def test_vector_environment_steps_and_auto_resets(oracle, kernel_choice):
     env.close()
 
 
-# rf_env_step's schedules (rf_abi.hip).  Default for the canonical camera: the step's two renders and two focus
+# rf_env_step's schedules (rf_abi_env.hip).  Default for the canonical camera: the step's two renders and two focus
 # measures as ONE launch each -- the environments that end are ranked before the render (the flags depend on their
 # counters alone) and the blocks of the slots whose RNG streams the re-rendered frames continue make two passes --
 # enqueued in one go ("fused") and replayed as one hipGraph from the second step on ("fused-graph").  With
@@ -612,7 +612,7 @@ def test_fused_step_on_the_test_builds_of_the_library(build, height, tmp_path):
 
 
 def test_small_environments_take_the_one_pixel_kernel(monkeypatch):
-    """The library's own choice for launches of few blocks (rf_abi.hip few_blocks: the reference's default single
+    """The library's own choice for launches of few blocks (rf_abi_render.hip few_blocks: the reference's default single
     environment among them): the kernel without cooperative tails, in its two-pass form inside the fused step -- a
     device-resident environment of 3 x 64 x 64 at 8 samples, equal to the numpy glue."""
     from reinfocus_amd.environments import harness

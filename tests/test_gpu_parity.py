@@ -167,7 +167,7 @@ def test_render_general_camera_matches_oracle(ctx, oracle, h, w):
 @pytest.mark.parametrize("h", [64, 60])
 def test_lens_radius_forms(ctx, oracle, lens, h):
     """offset = float32(float64(p) * lens_radius) (camera.py:343): the canonical-frame kernels
-    use a float32 fma form when the host finds it exact for the radius (rf_abi.hip lens_split)
+    use a float32 fma form when the host finds it exact for the radius (rf_abi_ctx.hip lens_split)
     and the literal float64 form otherwise -- e.g. for the first two radii here, for which 1 / 5
     of the 25 M possible disc coordinates round differently (tests/test_hostsim.py)."""
     n, spp = 3, 6
@@ -184,7 +184,7 @@ def test_lens_radius_forms(ctx, oracle, lens, h):
 @pytest.mark.parametrize("h,w", [(8, 8), (6, 10)])
 def test_more_environments_than_one_launch_holds(ctx, oracle, h, w):
     """A launch's grid holds 65 535 environments: larger batches are rendered and scored in chunks
-    (launch_render / launch_focus, rf_abi.hip).  65 600 environments -- frames, final RNG states and
+    (launch_render / launch_focus, rf_abi_render.hip).  65 600 environments -- frames, final RNG states and
     focus values of every one of them, on both sides of the chunk boundary, against the oracle; the
     6 x 10 frame takes the byte-store path (w % 4 != 0) with a chunk base that is not dword-aligned."""
     n, spp = 65_600, 2

@@ -114,7 +114,7 @@ def test_lens_offset_float32_form(hs):
     """offset = float32(float64(p) * lens_radius): for the reference's aperture 0.1 (radius
     numpy.divide(0.1, 2.0) = 0.05) the float32 fma form is exact for all 25 165 825 possible disc
     coordinates; radii for which it is not exist, and the C ABI then keeps the float64 form (the
-    same exhaustive check runs in rf_abi.hip lens_split)."""
+    same exhaustive check runs in rf_abi_ctx.hip lens_split)."""
     assert hs.hs_check_lens(float(np.divide(0.1, 2.0))) == 0
     assert hs.hs_check_lens(0.0625) == 0  # a power of two scales exactly
     # about one radius in twelve has a few coordinates that round differently, e.g.:
