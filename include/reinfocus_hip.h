@@ -125,9 +125,10 @@ const char *rf_render_kernel_name(rf_ctx *ctx);
  * it, so that per-pixel figures count the pixels really rendered (not waves x pixels per wave). */
 unsigned long long rf_pixels_rendered(void);
 
-/* Pixels the last launch of the ctx's last rf_render_general left to its fix-up kernel (one-shape worlds: the
- * pixels the cooperative kernel could not decide in float32, rendered again by the literal code; csrc/rf_general_one.h);
- * 0 for other worlds and before the first call.  No reference counterpart (tools/bench_general.py reports the share). */
+/* Pixels the launches of the ctx's last rf_render_general call left to the fix-up kernel, summed over the call's launches:
+ * the pixels the one-shape or the dense kernel could not decide in float32 and the literal code rendered again
+ * (csrc/rf_general_one.h, rf_general_dense.h); 0 for calls the literal kernel served and before the first call.
+ * No reference counterpart (tools/bench_general.py reports the share). */
 unsigned rf_general_redo_pixels(rf_ctx *ctx);
 
 /* Blocks until everything enqueued on the ctx's stream has finished. */

@@ -287,14 +287,9 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                     continue;
                 const int e0 = c * chunk, ne = std::min(chunk, n - e0);
                 const uint64_t first = (uint64_t)e0 * hw64, count = (uint64_t)ne * hw64;
-                if (ctx->d_seed_cache && ctx->seed_cache_n == ctx->n_states) {
-                    RF_HIP(hipMemcpyAsync(ctx->d_states + first, ctx->d_seed_cache + first, count * sizeof(ulonglong2),
-                                          hipMemcpyDeviceToDevice, ctx->stream));
-                } else {
-                    rc = seed_range(ctx, first, count, 0, first);
-                    if (rc != RF_OK)
-                        return rc;
-                }
+                rc = seed_range(ctx, first, count, 0, first); // (the jump-ahead kernel, not the remembered copy: one path, rarely taken)
+                if (rc != RF_OK)
+                    return rc;
                 launch_literal(chunk_args(e0, ne));
                 RF_HIP(hipGetLastError());
             }

@@ -24,8 +24,8 @@
 //     relative from every rounding boundary (the reference's own float64 roundings move its value by < 2^-50).
 //   * rectangle.hit is float32 in the reference (IEEE division: kept); texture coordinates by the correctly rounded
 //     three-operation quotient (rf_math.h div_by_const) where the extent allows.
-//   * checker colours: the float32 decisions of rf_general_one.h (checker_sign_quick, sphere_red_quick), which abstain
-//     where the literal code would consult float64.
+//   * checker colours: float32 decisions (checker_sign_dense, sphere_red_dense: rf_general.h's own float32 tests and
+//     margins) which abstain where the literal code would consult float64.
 //   * the sky is float32 in every kernel (rf_math.h: proven equal to the float64 chain).
 //
 // NS: the most shapes an environment of the launch holds (1 ... 3; the reference's shape factories build one or two); an

@@ -70,43 +70,8 @@ __device__ __forceinline__ void general_ray_scalar(const_as<GeneralCamera> &cam,
     }
 }
 
-// RF_TEST_DOUBT (tests/gpucheck/libreinfocus_doubt.so, tests/test_gpu_general.py): the abstention path is taken about
-// once in 10^4 pixels and a decision inside the margin is still right almost always, so a pixel that abstains without
-// being listed would go unnoticed.  The test build makes every abstention visible: the margin of the checker test is
-// 2^-4 (a fifth of all decisions abstain) and a decision that abstains returns the WRONG sign; one scattered ray in
-// sixteen counts as grazing and has its direction mirrored.  Frames and RNG states must still equal the oracle's.
-#ifndef RF_TEST_DOUBT
-#define RF_TEST_DOUBT 0
-#endif
-
-// checker_sign_general's float32 decision, or abstention (rf_general.h: same expressions, same margin)
-__device__ __forceinline__ int checker_sign_quick(float f, float u, bool &doubt)
-{
-    const float m = f * u;
-    const float fl = __builtin_floorf(m);
-    const float fr = m - fl;
-    const float am = __builtin_fabsf(m);
-    const float margin = (am > 1.0f ? am : 1.0f) * (RF_TEST_DOUBT ? 0.0625f : 9.5367431640625e-07f); // 2^-20
-    const bool quick = am < 65536.0f && fr > margin && fr < 1.0f - margin; // false for NaN
-    doubt = doubt || !quick;
-    const int sign = ((int)fl & 1) ? -1 : 1;
-    return (RF_TEST_DOUBT && !quick) ? -sign : sign;
-}
-
-// sphere_red's float32 decision (rf_general.h: same expressions, same margins), or abstention
-__device__ __forceinline__ bool sphere_red_quick(const float n[3], float fu, float fv, bool &doubt)
-{
-    float u, v;
-    sphere_uv_approx(n, u, v);
-    const float mu = fu * u, mv = fv * v;
-    int odd_u, odd_v;
-    const float slack = RF_TEST_DOUBT ? 750.0f : 1.0f; // (the test build: about a fifth of the decisions abstain)
-    const bool quick_u = safe_parity(mu, (__builtin_fabsf(fu) + __builtin_fabsf(mu) + 1.0f) * 2e-6f * slack, odd_u);
-    const bool quick_v = safe_parity(mv, (__builtin_fabsf(fv) + __builtin_fabsf(mv) + 1.0f) * 2e-6f * slack, odd_v);
-    const bool quick = quick_u && quick_v;
-    doubt = doubt || !quick;
-    return (odd_u == odd_v) != (RF_TEST_DOUBT && !quick); // (the test build: an abstention's answer is wrong)
-}
+// (the float32 decisions that abstain -- checker_sign_dense, sphere_red_dense -- and the RF_TEST_DOUBT build that makes every
+// abstention frequent and visibly wrong: rf_general_dense.h)
 
 constexpr int kGeneralOneOcc = 6; // waves per SIMD the register allocator is held to (5 ... 7 measured: within 1 %)
 // SPHERE: the environment's one shape is a sphere (sphere.py:40-117) instead of a rectangle.  A ray that scattered off
@@ -264,7 +229,7 @@ render_general_one_kernel(GeneralOneArgs ra)
                     hit = sphere_hit(sp, o, d, t_min, t_max, rec);
                 hit_m[j] = live_m[j] & lanes_where(hit);
                 if (lane_in(hit_m[j]))
-                    red = sphere_red_quick(rec.n, sfreq_u, sfreq_v, doubt);
+                    red = sphere_red_dense(rec.n, sfreq_u, sfreq_v, doubt);
                 red_m[j] = hit_m[j] & lanes_where(red);
                 doubt_m[j] = hit_m[j] & lanes_where(doubt);
 #pragma unroll
@@ -292,7 +257,7 @@ render_general_one_kernel(GeneralOneArgs ra)
                     u = (px - x_min) / den_u;
                     v = (py - y_min) / den_v;
                 }
-                red = checker_sign_quick(freq_u, u, doubt) * checker_sign_quick(freq_v, v, doubt) > 0;
+                red = checker_sign_dense(freq_u, u, doubt) * checker_sign_dense(freq_v, v, doubt) > 0;
             }
             rd[j][0] = hit ? z_pos - pz : d[0];
             rd[j][1] = hit ? (red ? 1.0f : 0.0f) : d[1];
