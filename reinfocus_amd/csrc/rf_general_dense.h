@@ -1,5 +1,6 @@
 // rf_general_dense.h -- the general renderer for worlds of a few shapes per environment, without
-// float64 code: render_general_dense_kernel<POW2, NS>.
+// float64 sequences: render_general_dense_kernel<POW2, NS, TILED, SIMPLE> (the kernel itself: rf_general_one.h, next to the
+// fix-up kernel it shares with the one-shape kernel).
 //
 // Why.  The literal kernel (rf_general_kernels.h) is held to 5 waves per SIMD by what its float64 pieces need while they
 // run -- the sphere's roots (sqrt and two divisions), the camera's lens products, the out-of-line atan2 / acos / sin of the
@@ -18,10 +19,11 @@
 //     sixteen inline instructions with nothing to decide.
 //   * sphere.hit (sphere.py:40-103).  a, b, c and the discriminant are the reference's float32 expressions.  A negative
 //     discriminant and the certain miss of rf_general.h are exact decisions.  Otherwise root = (-b -+ sqrt(disc)) / a is
-//     evaluated in double-float with a relative error below 2^-43 (bound and measurement: sphere_root_df below); the
-//     comparisons with t_min / t_max abstain within 2^-20 relative of the bound, and each of the four roundings to
-//     float32 -- t and the three products d_k * root -- abstains unless the double-float value is further than 2^-41
-//     relative from every rounding boundary (the reference's own float64 roundings move its value by < 2^-50).
+//     evaluated in double-float with a relative error below 2^-43 (kappa + 1), kappa the cancellation of its numerator
+//     (bound and measurement: sphere_root_df below); the comparisons with t_min / t_max abstain within 2^-20 relative of
+//     the bound, and each of the four roundings to float32 -- t and the three products d_k * root -- abstains unless the
+//     double-float value is further than 2^-41 (kappa + 1) relative from every rounding boundary (4x the error bound; the
+//     reference's own float64 roundings move its value by < 2^-50 (kappa + 1)).
 //   * rectangle.hit is float32 in the reference (IEEE division: kept); texture coordinates by the correctly rounded
 //     three-operation quotient (rf_math.h div_by_const) where the extent allows.
 //   * checker colours: float32 decisions (checker_sign_dense, sphere_red_dense: rf_general.h's own float32 tests and
