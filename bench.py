@@ -685,18 +685,23 @@ def main(argv=None):
     action_rng = np.random.Generator(np.random.PCG64DXSM(1000 + ranks.rank))
 
     gathered_bytes = [0]
+    gather_seconds = [0.0]  # (rank 0's time inside the gather: waiting for the slowest rank included)
+
+    def gather_step(*arrays):
+        t_gather = time.perf_counter()
+        gathered_bytes[0] = ranks.gather_step(*arrays)
+        gather_seconds[0] += time.perf_counter() - t_gather
 
     def one_step():
         actions = action_rng.integers(0, 13, n_here)
         if env is None:  # (plumbing: a fake block goes through the same gather)
             time.sleep(0.002)
-            gathered_bytes[0] = ranks.gather_step(np.zeros((n_here, 4), np.float32), np.zeros(n_here), np.zeros(n_here, bool),
-                                                  np.ones(n_here, bool))
+            gather_step(np.zeros((n_here, 4), np.float32), np.zeros(n_here), np.zeros(n_here, bool), np.ones(n_here, bool))
             return 0
         obs, rewards, term, trunc, _ = env.step(actions)
         # one process per GPU: the ranks' blocks are gathered on rank 0, as the one vector environment they stand for would
         # return them (the sharded product object concatenates inside step() itself)
-        gathered_bytes[0] = ranks.gather_step(obs, rewards, term, trunc)
+        gather_step(obs, rewards, term, trunc)
         return int((term | trunc).sum())
 
     for _ in range(args.warmup):
@@ -714,6 +719,7 @@ def main(argv=None):
             on_contexts(lambda c: c.timing(True))
         on_contexts(lambda c: c.synchronize())
     ranks.barrier()
+    gather_seconds[0] = 0.0
     t0 = time.perf_counter()
     resets = 0
     for _ in range(args.steps):
@@ -771,6 +777,8 @@ def main(argv=None):
                             ", no data-path collective",
                 # what rank 0 holds after a step: N x 29 B (value = all ranks' environments / the time to step AND gather them)
                 "host_gather_bytes_per_step": gathered_bytes[0],
+                # rank 0's share of a step spent in that gather (the wait for the slowest rank's step included)
+                "host_gather_ms_per_step": 1000.0 * gather_seconds[0] / max(args.steps, 1),
                 "env_glue": {"device": "device-resident (rf_env_step)", "host": "host numpy (harness), frames stay in HBM",
                              "literal": "host numpy (harness) over the literal stub: rf_render(host_out) + "
                                         "rf_upload_frames + rf_focus, frames cross PCIe twice per render"}[args.env],
