@@ -217,9 +217,9 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             d.shapes = (const rf::ShapeConst *)(scratch + o_shp) + (size_t)e0 * most;
             d.simple_cameras = simple_cameras ? 1 : 0;
             d.fc = rf::frame_const(h, w);
-            // (the fix-up kernel: kFixupLanes pixels per wave, grid-stride; 4096 blocks hold 16 K waves)
-            const uint64_t blocks = ((uint64_t)ne * hw64 + rf::kFixupLanes * 4 - 1) / (rf::kFixupLanes * 4);
-            const dim3 fix((unsigned)std::min<uint64_t>(blocks, 4096));
+            // (the fix-up kernel: grid-stride over the list; a launch of few pixels needs fewer blocks than the full grid)
+            const uint64_t blocks = ((uint64_t)ne * hw64 + 3) / 4;
+            const dim3 fix((unsigned)std::min<uint64_t>(blocks, rf::kFixupBlocks));
             if (kind == kDense) {
                 // 16 x 16 tiles (waves of 8 x 8 pixels) unless they pad the frame much more than 256-pixel runs do (frames
                 // narrower or lower than a tile)

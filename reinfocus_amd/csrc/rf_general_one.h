@@ -421,23 +421,30 @@ render_general_one_kernel(GeneralOneArgs ra)
 }
 
 // The listed pixels, literally (rf_general.h render_pixel_general: float64 sines where float32 cannot decide, any
-// number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it
-// reads itself.  The list is short (a launch's pixels / 10^3) and the kernel's duration is the latency of ONE pixel's
-// samples, most of it the in-wave rejection loops' max-over-lanes trips: kFixupLanes pixels per wave instead of 64 shorten
-// those (RF_FIXUP_LANES 64 / 32 / 16 / 8: profiles/r05_ab.txt section 10), the registers are unbounded (no spills).
-#ifndef RF_FIXUP_LANES
-#define RF_FIXUP_LANES 32
+// number of bounces).  Runs after the first kernel on the same stream; grid-stride over the list, whose length it reads
+// itself.  The list is short (a launch's pixels / 10^3) and the kernel's duration is the LATENCY of one pixel's samples
+// -- about 5 us per sample for a wave, whatever it executes and however many lanes it has (profiles/r05_ab.txt section
+// 13: 80 us at 16 samples, 0.5 ms at 100).  A wave takes as few pixels as still lets every listed pixel's wave be
+// resident at once (kFixupWaves waves, about two per SIMD: 1 ... 64 pixels per wave, chosen from the list's length):
+// fewer unrelated pixels per wave, fewer max-over-lanes trips (-10 ... -18 % of this kernel's time against a fixed 32).
+// The registers are unbounded (no spills).
+#ifndef RF_FIXUP_WAVES
+#define RF_FIXUP_WAVES 2048
 #endif
-constexpr unsigned kFixupLanes = RF_FIXUP_LANES;
+constexpr unsigned kFixupWaves = RF_FIXUP_WAVES;
+constexpr unsigned kFixupBlocks = 1024; // the grid: 4 096 waves, all resident (124 registers: 4 waves per SIMD)
 template <bool POW2>
 __global__ __launch_bounds__(kBlock) void render_general_fixup_kernel(GeneralOneArgs ra)
 {
     const GeneralArgs &a = ra.g;
     const unsigned total = min(*ra.redo_count, ra.redo_cap); // (more than the list holds: the host renders the launch again)
     const unsigned lane = threadIdx.x & 63u, wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, waves = gridDim.x * (kBlock / 64);
-    if (lane >= kFixupLanes)
+    unsigned lanes = 1; // pixels per wave
+    while (lanes < 64u && (total + lanes - 1) / lanes > kFixupWaves)
+        lanes <<= 1;
+    if (lane >= lanes)
         return;
-    for (unsigned i = wave * kFixupLanes + lane; i < total; i += waves * kFixupLanes) {
+    for (unsigned i = wave * lanes + lane; i < total; i += waves * lanes) {
         const unsigned pix = ra.redo_list[i];
         const int e = (int)(pix / (unsigned)a.hw), p = (int)(pix - (unsigned)e * (unsigned)a.hw);
         const int y = p / a.w, x = p - y * a.w;
