@@ -4,7 +4,7 @@ one-shape and dense kernels.  Each is timed with HIP events on the context's own
 launches at a size that fills the device (the best of four counts), and must reach FLOOR x the rate recorded in profiles/r05_perf_guard.json --
 measured by this very test on the round-5 tree (REINFOCUS_PERF_GUARD_RECORD=<file> writes what a run measures).  The kernel
 each launch took is asserted too: a change of the dispatch that sends a shape to another kernel shows up by name.  The
-floor (0.93) is wide enough for the boxes of the pool (the same build measures within +-2 % on different boxes, kernel time),
+floor (0.90) is wide enough for the boxes of the pool (the same build measured up to 4 % apart on different boxes, kernel time),
 and narrow enough for what a careless edit costs: see profiles/r05_ab.txt section 5 for the builds it was tried on."""
 
 import json
@@ -19,7 +19,7 @@ from tests.test_general_renderer import _factory_worlds
 pytestmark = pytest.mark.gpu
 
 RECORD = os.path.join(helpers.ROOT, "profiles", "r05_perf_guard.json")
-FLOOR = 0.93
+FLOOR = 0.90
 
 
 def _measure():
