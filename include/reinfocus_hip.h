@@ -125,6 +125,11 @@ const char *rf_render_kernel_name(rf_ctx *ctx);
  * it, so that per-pixel figures count the pixels really rendered (not waves x pixels per wave). */
 unsigned long long rf_pixels_rendered(void);
 
+/* 1 when the process started with REINFOCUS_POISON_ALLOC in its environment: every device / pinned-host allocation of the
+ * library is then filled with 0xA5 bytes before use (csrc/rf_host.h dev_malloc) -- a debugging aid under which the GPU test
+ * suite runs, so that no result can depend on what fresh or recycled memory holds.  No reference counterpart. */
+int rf_allocations_poisoned(void);
+
 /* Pixels the launches of the ctx's last rf_render_general call left to the fix-up kernel, summed over the call's launches:
  * the pixels the one-shape or the dense kernel could not decide in float32 and the literal code rendered again
  * (csrc/rf_general_one.h, rf_general_dense.h); 0 for calls the literal kernel served and before the first call.

@@ -63,6 +63,7 @@ SYMBOLS = (
     "rf_env_last_step_branch",
     "rf_render_kernel_name",
     "rf_pixels_rendered",
+    "rf_allocations_poisoned",
     "rf_general_redo_pixels",
 )
 
@@ -157,6 +158,8 @@ def load():
     lib.rf_render_kernel_name.argtypes = [vp]
     lib.rf_pixels_rendered.restype = ctypes.c_ulonglong
     lib.rf_pixels_rendered.argtypes = []
+    lib.rf_allocations_poisoned.restype = ctypes.c_int
+    lib.rf_allocations_poisoned.argtypes = []
     lib.rf_general_redo_pixels.restype = ctypes.c_uint
     lib.rf_general_redo_pixels.argtypes = [vp]
     _lib = lib
@@ -228,6 +231,11 @@ def pin_to_numa_node(node, whole_process=False, sysfs="/sys/devices/system/node"
 def pixels_rendered():
     """Pixels all render launches of this process were made for (rf_pixels_rendered)."""
     return int(load().rf_pixels_rendered())
+
+
+def allocations_poisoned():
+    """True when the library fills its allocations with 0xA5 bytes first (REINFOCUS_POISON_ALLOC; rf_allocations_poisoned)."""
+    return bool(load().rf_allocations_poisoned())
 
 
 def default_device():

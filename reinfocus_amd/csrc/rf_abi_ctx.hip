@@ -218,12 +218,12 @@ int rf_create(int device, rf_ctx **out)
     }
     hipError_t he = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (he == hipSuccess)
-        he = hipMalloc((void **)&ctx->d_mats, sizeof(rf::Mat128) * rf::kSeedMats);
+        he = dev_malloc((void **)&ctx->d_mats, sizeof(rf::Mat128) * rf::kSeedMats);
     if (he == hipSuccess)
         he = hipMemcpy(ctx->d_mats, tables.data(), sizeof(rf::Mat128) * rf::kSeedMats,
                        hipMemcpyHostToDevice);
     if (he == hipSuccess)
-        he = hipMalloc((void **)&ctx->d_zero, 256);
+        he = dev_malloc((void **)&ctx->d_zero, 256);
     if (he == hipSuccess)
         he = hipMemset(ctx->d_zero, 0, 256);
     if (he != hipSuccess) {
@@ -283,7 +283,7 @@ int rf_seed(rf_ctx *ctx, uint64_t n_states, uint64_t seed, uint64_t first_state_
             RF_HIP(hipFree(ctx->d_states));
         ctx->d_states = nullptr;
         ctx->n_states = 0;
-        RF_HIP(hipMalloc((void **)&ctx->d_states, n_states * sizeof(ulonglong2)));
+        RF_HIP(dev_malloc((void **)&ctx->d_states, n_states * sizeof(ulonglong2)));
         ctx->n_states = n_states;
     }
     return rfh::seed_range(ctx, 0, n_states, seed, first_state_index);
@@ -336,8 +336,8 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
         if (ctx->d_rect) RF_HIP(hipFree(ctx->d_rect));
         ctx->d_cam = ctx->d_rect = nullptr;
         ctx->scene_cap = 0;
-        RF_HIP(hipMalloc((void **)&ctx->d_cam, (size_t)n * 9 * sizeof(float)));
-        RF_HIP(hipMalloc((void **)&ctx->d_rect, (size_t)n * 2 * sizeof(float)));
+        RF_HIP(dev_malloc((void **)&ctx->d_cam, (size_t)n * 9 * sizeof(float)));
+        RF_HIP(dev_malloc((void **)&ctx->d_rect, (size_t)n * 2 * sizeof(float)));
         ctx->scene_cap = n;
     }
     RF_HIP(hipMemcpyAsync(ctx->d_cam, cam_dyn, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice,
@@ -371,6 +371,7 @@ int rf_set_scene(rf_ctx *ctx, int n, const float *cam_dyn, const float *rect,
 }
 
 unsigned long long rf_pixels_rendered(void) { return g_pixels_rendered.load(); }
+int rf_allocations_poisoned(void) { return poison_allocations() ? 1 : 0; }
 
 int rf_synchronize(rf_ctx *ctx)
 {

@@ -66,7 +66,7 @@ int rf_env_configure(rf_ctx *ctx, const rf_env_config *cfg)
                  o_drank = take(n * 4);
     const EnvIo io(n);
     const size_t o_io = take(io.bytes);
-    RF_HIP(hipMalloc(&ctx->env_block, off));
+    RF_HIP(dev_malloc(&ctx->env_block, off));
     RF_HIP(hipMemsetAsync(ctx->env_block, 0, off, ctx->stream));
     char *base = (char *)ctx->env_block;
     rf::EnvState &s = ctx->env;
@@ -355,7 +355,7 @@ int rf_env_step(rf_ctx *ctx, const int32_t *host_actions, const float *host_pool
                     RF_HIP(hipHostFree(ctx->h_stage));
                 ctx->h_stage = nullptr;
                 ctx->h_stage_bytes = 0;
-                RF_HIP(hipHostMalloc((void **)&ctx->h_stage, bytes, hipHostMallocDefault));
+                RF_HIP(host_malloc((void **)&ctx->h_stage, bytes));
                 ctx->h_stage_bytes = bytes;
             }
             uint8_t *st = ctx->h_stage;

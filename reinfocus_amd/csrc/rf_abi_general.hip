@@ -35,7 +35,7 @@ int seed_zero_cached(rf_ctx *ctx, uint64_t n_states)
             RF_HIP(hipFree(ctx->d_seed_cache));
         ctx->d_seed_cache = nullptr;
         ctx->seed_cache_n = 0;
-        if (hipMalloc((void **)&ctx->d_seed_cache, n_states * sizeof(ulonglong2)) != hipSuccess) {
+        if (dev_malloc((void **)&ctx->d_seed_cache, n_states * sizeof(ulonglong2)) != hipSuccess) {
             (void)hipGetLastError(); // no room for the copy: keep seeding every time
             ctx->d_seed_cache = nullptr;
             return RF_OK;
@@ -146,7 +146,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             RF_HIP(hipFree(ctx->general_scratch));
         ctx->general_scratch = nullptr;
         ctx->general_scratch_bytes = 0;
-        RF_HIP(hipMalloc(&ctx->general_scratch, total));
+        RF_HIP(dev_malloc(&ctx->general_scratch, total));
         ctx->general_scratch_bytes = total;
     }
     char *const scratch = (char *)ctx->general_scratch;

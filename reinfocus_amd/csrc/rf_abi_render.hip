@@ -71,7 +71,7 @@ int ensure_frames(rf_ctx *ctx, int n, int h, int w)
             RF_HIP(hipFree(ctx->d_frames));
         ctx->d_frames = nullptr;
         ctx->frames_cap = 0;
-        RF_HIP(hipMalloc((void **)&ctx->d_frames, need));
+        RF_HIP(dev_malloc((void **)&ctx->d_frames, need));
         ctx->frames_cap = need;
     }
     ctx->fn = n;
@@ -88,7 +88,7 @@ int ensure_frames2(rf_ctx *ctx, int n, int h, int w)
             RF_HIP(hipFree(ctx->d_frames2));
         ctx->d_frames2 = nullptr;
         ctx->frames2_cap = 0;
-        RF_HIP(hipMalloc((void **)&ctx->d_frames2, need));
+        RF_HIP(dev_malloc((void **)&ctx->d_frames2, need));
         ctx->frames2_cap = need;
     }
     return RF_OK;
@@ -266,8 +266,8 @@ int ensure_focus(rf_ctx *ctx, int n)
     ctx->d_var = nullptr;
     ctx->env.sums = nullptr;
     ctx->focus_cap = 0;
-    RF_HIP(hipMalloc((void **)&ctx->d_sums, (size_t)n * 2 * sizeof(unsigned long long)));
-    RF_HIP(hipMalloc((void **)&ctx->d_var, (size_t)n * sizeof(double)));
+    RF_HIP(dev_malloc((void **)&ctx->d_sums, (size_t)n * 2 * sizeof(unsigned long long)));
+    RF_HIP(dev_malloc((void **)&ctx->d_var, (size_t)n * sizeof(double)));
     ctx->focus_cap = n;
     ctx->env.sums = ctx->d_sums;
     return RF_OK;

@@ -9,6 +9,7 @@
 //
 // Every kernel is defined in exactly one unit (the one that launches it); the units share only host functions.
 #pragma once
+#include <cstring>
 
 #include "../../include/reinfocus_hip.h"
 
@@ -183,5 +184,30 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
 int ensure_focus(rf_ctx *ctx, int n);
 int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect = nullptr, bool in_env_step = false,
                  const int *fused_count = nullptr);
+
+// hipMalloc / hipHostMalloc.  With REINFOCUS_POISON_ALLOC in the environment (tests/conftest.py sets it for the whole GPU suite)
+// every allocation is filled with 0xA5 bytes first: nothing may depend on what fresh -- or recycled -- memory happens to hold.
+inline bool poison_allocations()
+{
+    static const bool poison = getenv("REINFOCUS_POISON_ALLOC") != nullptr;
+    return poison;
+}
+inline hipError_t dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && bytes && poison_allocations()) {
+        e = hipMemset(*p, 0xA5, bytes);
+        if (e == hipSuccess)
+            e = hipDeviceSynchronize(); // (the ctx's stream does not wait for the null stream)
+    }
+    return e;
+}
+inline hipError_t host_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess && bytes && poison_allocations())
+        memset(*p, 0xA5, bytes);
+    return e;
+}
 
 } // namespace rfh

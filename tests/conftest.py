@@ -21,6 +21,10 @@ def pytest_configure(config):
     os.environ.setdefault("REINFOCUS_GENERAL_ONE", "1")
     # and its dense kernel for worlds of up to three shapes (the library: launches of more than 2 M pixels)
     os.environ.setdefault("REINFOCUS_GENERAL_DENSE", "1")
+    # every device / pinned-host allocation of the library starts as 0xA5 bytes (csrc/rf_host.h dev_malloc): a result that
+    # depends on what fresh or recycled memory holds -- a list not cleared, a sum not zeroed -- fails here instead of in a
+    # long-lived process (smoke() and bench.py run without it)
+    os.environ.setdefault("REINFOCUS_POISON_ALLOC", "1")
 
 
 def pytest_sessionstart(session):

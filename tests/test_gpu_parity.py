@@ -41,6 +41,13 @@ def test_seed_matches_sequential_jumps(ctx, oracle, n, first):
     assert np.array_equal(ctx.get_states(), want)
 
 
+def test_the_suite_runs_on_poisoned_allocations(native):
+    """tests/conftest.py starts the session with REINFOCUS_POISON_ALLOC: every buffer the library allocates holds 0xA5 bytes
+    before its first use, so a kernel that reads a list nobody cleared or a sum nobody zeroed cannot pass by the luck of a
+    fresh page (the same library without the variable: smoke(), bench.py)."""
+    assert native.allocations_poisoned()
+
+
 def test_seed_far_offset(ctx):
     """State indices beyond what the sequential oracle can reach in seconds (the 8-GPU
     shard offsets): compare with the host GF(2) tables, which tests/test_host_logic.py
