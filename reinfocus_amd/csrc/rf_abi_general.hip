@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <set>
 #include <vector>
 
 #include "rf_general_one.h"
@@ -101,12 +102,24 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                      (ctx->general_one_always || pixels > (one_sphere ? 3000000u : 2000000u));
     for (int e = 0; one_shape && e < n; ++e)
         one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
+    // every camera: canonical axes (cheap, first) and a lens radius whose float32 offset is proven exact -- a proof costs
+    // ~60 ms of host time once per radius and process (lens_split), so a launch with more than a handful of different
+    // apertures is not worth it: it takes the instances with the reference's float64 lens products
     auto cameras_simple = [&]() {
+        std::set<double> radii;
         for (int e = 0; e < n; ++e) {
+            const double radius = cams[(size_t)e].lens_radius;
+            if (!rf::camera_axes_simple(cams[(size_t)e]) || !(radius == radius))
+                return false;
+            radii.insert(radius);
+            if (radii.size() > 4)
+                return false;
+        }
+        for (const double radius : radii) {
             rf::CamStatic probe{};
-            probe.lens_radius = cams[(size_t)e].lens_radius;
+            probe.lens_radius = radius;
             lens_split(probe); // (remembered per radius)
-            if (probe.lens_f32 == 0 || !rf::camera_axes_simple(cams[(size_t)e]))
+            if (probe.lens_f32 == 0)
                 return false;
         }
         return true;

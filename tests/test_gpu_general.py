@@ -383,8 +383,8 @@ def test_few_shape_worlds_take_the_dense_kernel_and_match_the_oracle(ctx, oracle
 def test_which_worlds_take_which_dense_instance(ctx, oracle):
     """Up to three shapes per environment, any counts: the dense kernel -- its SIMPLE instances (float32 lens offset) when
     every camera has canonical axes and a lens radius whose float32 offset rf_abi_ctx.hip lens_split finds exact, the
-    instances with the reference's float64 lens products for tilted cameras and other radii; four shapes: the literal
-    kernel.  The oracle's frames either way."""
+    instances with the reference's float64 lens products for tilted cameras, other radii and launches with more than four
+    different radii; four shapes: the literal kernel.  The oracle's frames either way."""
     from reinfocus_amd.graphics import camera, shape_factory as sf, world
 
     two = sf.two_sphere(sf.ShapeParameters(12.0), sf.ShapeParameters(6.0))
@@ -410,6 +410,9 @@ def test_which_worlds_take_which_dense_instance(ctx, oracle):
     for aperture, simple in ((2 * 0.6243510725689605, False), (2 * 0.46456785704581477, False), (0.14, True), (0.125, True)):
         cams = camera.Cameras(camera.make_gpu_camera(aperture=aperture), camera.make_gpu_camera(aperture=aperture))
         check(cams, p, t, s, "render_general_dense_kernel<false, 2", ", true>" if simple else ", false>")
+    # a proof per radius costs the host ~60 ms: a launch with more than four different apertures is not worth them
+    many = camera.Cameras(*[camera.make_gpu_camera(aperture=0.1 + 0.01 * k) for k in range(5)])
+    check(many, *world.Worlds(two, two, two, two, two).device_data(), "render_general_dense_kernel<false, 2", ", false>")
 
 
 def test_a_fix_up_list_that_overflows_is_rendered_again_by_the_literal_kernel(oracle, tmp_path):
