@@ -58,6 +58,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                       const int32_t *types, const int32_t *sizes, int most, int width, uint8_t *host_out)
 {
     RF_REQUIRE(ctx != nullptr && cameras && params && types && sizes, "rf_render_general: NULL argument");
+    RF_HIP(hipSetDevice(ctx->device));
     drop_env_graph(ctx);
     RF_REQUIRE(n > 0 && h > 0 && w > 0 && spp > 0 && most > 0 && width >= 7, "rf_render_general: bad sizes");
     RF_REQUIRE((uint64_t)h * (uint64_t)w < (1ull << 31), "rf_render_general: frame too large");

@@ -80,3 +80,32 @@ def test_built_libraries_are_not_older_than_their_sources():
         rc = subprocess.call(["make", "-q", "-C", os.path.join(root, directory), target],
                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert rc == 0, f"{directory}: {target} is out of date -- run __graft_entry__.build()"
+
+
+def test_every_entry_point_that_touches_the_device_selects_it():
+    """One process may hold contexts on several GPUs (harness.ShardedVectorDiscreteSteps: a thread per device): an entry
+    point that allocates, copies or launches must make the ctx's device current first, whatever the calling thread used
+    last.  Source-level: every extern "C" definition of csrc/rf_abi_*.hip calls hipSetDevice itself or consists of calls
+    to entry points that do; the ones listed here touch no device."""
+    hostside = {"rf_device_count", "rf_device_info", "rf_num_states", "rf_env_last_step_branch", "rf_env_step_abort",
+                "rf_env_scene_len", "rf_last_error", "rf_pixels_rendered", "rf_allocations_poisoned", "rf_render_kernel_name",
+                "rf_general_redo_pixels", "rf_step", "rf_abi_version"}  # (rf_step = rf_render + rf_focus)
+    seen = set()
+    csrc = os.path.join(ROOT, "reinfocus_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not (name.startswith("rf_abi_") and name.endswith(".hip")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r"^(?:int|unsigned|unsigned long long|const char \*)\s*(rf_[a-z_0-9]+)\(", text, flags=re.M):
+            entry = m.group(1)
+            start = text.index("{", m.end())
+            depth, end = 0, start
+            while True:  # (the definition's closing brace)
+                depth += {"{": 1, "}": -1}.get(text[end], 0)
+                end += 1
+                if depth == 0:
+                    break
+            seen.add(entry)
+            if entry not in hostside:
+                assert "hipSetDevice(" in text[start:end], f"{name}: {entry} does not select its device"
+    assert seen == set(_declared_symbols()), sorted(seen ^ set(_declared_symbols()))
