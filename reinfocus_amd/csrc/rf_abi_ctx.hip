@@ -226,6 +226,8 @@ int rf_create(int device, rf_ctx **out)
         he = dev_malloc((void **)&ctx->d_zero, 256);
     if (he == hipSuccess)
         he = hipMemset(ctx->d_zero, 0, 256);
+    if (he == hipSuccess)
+        he = hipDeviceSynchronize(); // (a memset on the null stream, which the ctx's non-blocking stream does not wait for)
     if (he != hipSuccess) {
         set_err("rf_create: %s", hipGetErrorString(he));
         rf_destroy(ctx);
