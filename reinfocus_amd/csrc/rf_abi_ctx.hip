@@ -203,6 +203,10 @@ int rf_create(int device, rf_ctx **out)
         ctx->general_one = v[0] != '0', ctx->general_one_always = v[0] == '1';
     if (const char *v = getenv("REINFOCUS_ENV_GRAPH_FAIL"))
         ctx->env_graph_fail_once = v[0] == '1';
+    if (const char *v = getenv("REINFOCUS_FOCUS_KERNEL"))
+        ctx->focus_choice = !strcmp(v, "quad") ? 1 : !strcmp(v, "byte") ? 2 : 0;
+    if (const char *v = getenv("REINFOCUS_FOCUS_BAND"))
+        ctx->focus_band = atoi(v);
     if (const char *v = getenv("REINFOCUS_ENV_ONE_SYNC_MAX")) {
         char *end = nullptr;
         const long limit = strtol(v, &end, 10);

@@ -280,12 +280,14 @@ int ensure_focus(rf_ctx *ctx, int n)
 // fused_count != null: both measures of a fused environment step as one launch of 2 n rows (FocusArgs::count2)
 int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *skip_rect, bool in_env_step, const int *fused_count)
 {
-    // widths that are a multiple of 4 (and >= 4): four pixels per thread, 32-row bands
+    // Widths that are a multiple of 4 (>= 8): focus_kernel_roll, four pixels per lane and everything in registers; any
+    // other width: the byte-per-thread kernel over column tiles.  Both take frames of any size (vision.py:11-39 scores
+    // whatever it is handed).  REINFOCUS_FOCUS_KERNEL=quad / byte, REINFOCUS_FOCUS_BAND: rf_host.h.
+    const int focus_choice = ctx->focus_choice, focus_band = ctx->focus_band;
     const size_t lds_quad = (((size_t)(2 * rf::kBandQ + 6) * w) + 15) & ~(size_t)15;
-    const bool quad = (w & 3) == 0 && w >= 4 && lds_quad <= 64 * 1024;
-    const int band = quad ? rf::kBandQ : rf::kBand;
-    const size_t lds = quad ? lds_quad : ((((size_t)(2 * rf::kBand + 6) * w) + 15) & ~(size_t)15);
-    RF_REQUIRE(lds <= 64 * 1024, "rf_focus: frame width %d needs %zu B of LDS (max 65536)", w, lds);
+    const bool roll = (w & 3) == 0 && w >= 8 && focus_choice == 0;
+    const bool quad = !roll && (w & 3) == 0 && w >= 4 && lds_quad <= 64 * 1024 && focus_choice == 1;
+    const size_t lds_byte = ((size_t)(rf::kBand + 4) * (rf::kTileB + 4) + (size_t)(rf::kBand + 2) * (rf::kTileB + 2) + 15) & ~(size_t)15;
     int rc = ensure_focus(ctx, n);
     if (rc != RF_OK)
         return rc;
@@ -293,8 +295,24 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
         RF_HIP(hipMemsetAsync(ctx->d_sums, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
     {
         Timed timed(ctx, &ctx->ev_focus);
-        const int gx = (h + band - 1) / band;
         const int rows = fused_count ? 2 * n : n;
+        // focus_kernel_roll: rows per band.  A band of R rows reads R + 4 (the halo rows cost 4 / R), and a launch wants
+        // at least a few waves per SIMD: the largest of 64 / 32 / 16 / 8 that leaves 8192 waves, else 8.
+        const int groups = w >> 2;
+        const bool halo = roll && (64 % groups) != 0; // (groups >= 2 there)
+        int band = 8;
+        if (roll) {
+            for (int r = rf::kRollBandMax; r >= 8; r >>= 1) {
+                const uint64_t lanes = (uint64_t)((h + r - 1) / r) * groups;
+                const uint64_t waves = (lanes + (halo ? 61 : 63)) / (halo ? 62 : 64) * (uint64_t)rows;
+                if (waves >= 8192 || r == 8) {
+                    band = r;
+                    break;
+                }
+            }
+            if (focus_band >= 1 && focus_band <= rf::kRollBandMax)
+                band = focus_band;
+        }
         for (int e0 = 0; e0 < rows; e0 += 65535) {
             const int ne = (rows - e0) < 65535 ? (rows - e0) : 65535;
             rf::FocusArgs a;
@@ -310,10 +328,28 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
             a.sums2 = ctx->env.sums2;
             a.n_step = n;
             a.row0 = e0;
-            if (quad)
-                hipLaunchKernelGGL(rf::focus_kernel_quad, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
-            else
-                hipLaunchKernelGGL(rf::focus_kernel, dim3(gx, ne), dim3(rf::kBlock), lds, ctx->stream, a);
+            if (roll) {
+                rf::FocusRollArgs ra;
+                ra.f = a;
+                ra.dot = rf::gray_dot(a.gray15);
+                ra.band = band;
+                ra.groups = groups;
+                ra.bands = (h + band - 1) / band;
+                const uint64_t lanes = (uint64_t)ra.bands * groups;
+                const uint64_t gx = (lanes + (halo ? 61 : 63)) / (halo ? 62 : 64);
+                RF_REQUIRE(gx < (1ull << 31), "rf_focus: frame %d x %d too large", h, w);
+                if (halo)
+                    hipLaunchKernelGGL(rf::focus_kernel_roll<true>, dim3((unsigned)gx, ne), dim3(64), 0, ctx->stream, ra);
+                else
+                    hipLaunchKernelGGL(rf::focus_kernel_roll<false>, dim3((unsigned)gx, ne), dim3(64), 0, ctx->stream, ra);
+            } else if (quad) {
+                hipLaunchKernelGGL(rf::focus_kernel_quad, dim3((h + rf::kBandQ - 1) / rf::kBandQ, ne), dim3(rf::kBlock), lds_quad,
+                                   ctx->stream, a);
+            } else {
+                const uint64_t gx = (uint64_t)((h + rf::kBand - 1) / rf::kBand) * (uint64_t)((w + rf::kTileB - 1) / rf::kTileB);
+                RF_REQUIRE(gx < (1ull << 31), "rf_focus: frame %d x %d too large", h, w);
+                hipLaunchKernelGGL(rf::focus_kernel, dim3((unsigned)gx, ne), dim3(rf::kBlock), lds_byte, ctx->stream, a);
+            }
         }
         if (!in_env_step)
             hipLaunchKernelGGL(rf::focus_finalize, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_sums,

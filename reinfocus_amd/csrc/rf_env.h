@@ -26,10 +26,7 @@ namespace rf {
 // environment kernels take the variance from the sums themselves, which saves the replayed step a launch per measure
 __device__ __forceinline__ double env_variance(const EnvConfig &c, const unsigned long long *sums, int slot)
 {
-    const unsigned long long s1 = sums[2 * slot], s2 = sums[2 * slot + 1];
-    const unsigned __int128 num = (unsigned __int128)c.frame_pixels * s2 - (unsigned __int128)s1 * s1;
-    const double dn = (double)c.frame_pixels;
-    return (double)(unsigned long long)num / (dn * dn);
+    return variance_from_sums(c.frame_pixels, sums[2 * slot], sums[2 * slot + 1]);
 }
 
 

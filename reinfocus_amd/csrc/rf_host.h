@@ -65,6 +65,9 @@ struct rf_ctx {
     unsigned long long *d_sums = nullptr;
     double *d_var = nullptr;
     int focus_cap = 0;
+    int focus_choice = 0; // REINFOCUS_FOCUS_KERNEL=quad / byte: the round-2 kernel where its rows fit into LDS / the
+                          // byte-per-thread kernel, instead of focus_kernel_roll (A/B runs and tests)
+    int focus_band = 0;   // REINFOCUS_FOCUS_BAND=r: rows per band of focus_kernel_roll (default: by launch size)
 
     rf::CheckerTable tab{};
 

@@ -164,6 +164,19 @@ RF_HD float rng_uniform64(Rng &g)
 RF_HD float rng_uniform(Rng &g) { return rng_uniform64(g) * kTwoM64; } // exact scaling
 
 // ---------------------------------------------------------------------------
+// ndarray.var() of a frame's Laplacian (vision.py:25) from its exact integer sums S1 = sum x, S2 = sum x^2 over N pixels:
+// (N S2 - S1^2) / N^2.  The numerator is exact in 128 bits for any frame (x <= 255: below 2^16 N^2) and goes to float64
+// in two limbs -- one rounding below 2^64 (every frame up to 3.3 10^7 pixels: the value of one conversion), two above.
+// ---------------------------------------------------------------------------
+RF_HD double variance_from_sums(unsigned long long npix, unsigned long long s1, unsigned long long s2)
+{
+    const unsigned __int128 num = (unsigned __int128)npix * s2 - (unsigned __int128)s1 * s1;
+    const double hi = (double)(unsigned long long)(num >> 64), lo = (double)(unsigned long long)num;
+    const double dn = (double)npix;
+    return (hi * 18446744073709551616.0 + lo) / (dn * dn);
+}
+
+// ---------------------------------------------------------------------------
 // scene parameters
 // ---------------------------------------------------------------------------
 // rect[e].half of an environment slot that a launch has to skip: the device-resident env step

@@ -513,4 +513,10 @@ int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)
     return 0;
 }
 
+// focus_finalize / env_variance: the variance from the exact integer sums (rf_math.h variance_from_sums)
+double hs_variance_from_sums(unsigned long long npix, unsigned long long s1, unsigned long long s2)
+{
+    return variance_from_sums(npix, s1, s2);
+}
+
 } // extern "C"

@@ -246,13 +246,7 @@ def test_partial_render_reuses_low_state_indices(ctx, oracle):
 # --- focus -----------------------------------------------------------------------------------
 
 
-@pytest.mark.parametrize(
-    "n,h,w",
-    [(4, 64, 64), (3, 300, 300), (5, 33, 35), (2, 17, 100), (7, 2, 2), (3, 1, 9), (2, 9, 1), (1, 256, 256),
-     (2, 16, 16), (2, 15, 20), (1, 600, 600)],
-)
-@pytest.mark.parametrize("gray_mode", [15, 14])
-def test_focus_matches_oracle(ctx, oracle, n, h, w, gray_mode):
+def _focus_frames(n, h, w):
     rng = np.random.default_rng(h * 7 + w)
     frames = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
     # one smooth image so that the median/Laplacian see structure, one constant
@@ -260,12 +254,69 @@ def test_focus_matches_oracle(ctx, oracle, n, h, w, gray_mode):
     frames[0, :, :, 0] = (xx * 3 + yy * 5) % 256
     if n > 1:
         frames[1] = 77
+    return frames
+
+
+# widths that are multiples of 4 (>= 8) take focus_kernel_roll (with and without halo lanes: 64 % (w / 4)), the others the
+# byte-per-thread kernel over column tiles of 512; vision.py:11-39 scores whatever it is handed: wide frames too
+FOCUS_SHAPES = [(4, 64, 64), (3, 300, 300), (5, 33, 35), (2, 17, 100), (7, 2, 2), (3, 1, 9), (2, 9, 1), (1, 256, 256),
+                (2, 16, 16), (2, 15, 20), (1, 600, 600), (3, 70, 8), (2, 5, 12), (2, 37, 128), (1, 100, 512),
+                (2, 67, 36), (3, 1, 8), (2, 2, 24), (1, 64, 1024), (1, 40, 2048), (1, 24, 4100), (1, 17, 938),
+                (2, 3, 4), (1, 130, 1030)]
+
+
+@pytest.mark.parametrize("n,h,w", FOCUS_SHAPES)
+@pytest.mark.parametrize("gray_mode", [15, 14])
+def test_focus_matches_oracle(ctx, oracle, n, h, w, gray_mode):
+    frames = _focus_frames(n, h, w)
     ctx.upload_frames(frames)
     got = ctx.focus(n, h, w, gray_mode)
     want = oracle.focus_values(frames, gray_mode)
-    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
     if n > 1:
         assert got[1] == 0.0
+
+
+@pytest.mark.parametrize("switch", [("REINFOCUS_FOCUS_BAND", "8"), ("REINFOCUS_FOCUS_BAND", "16"),
+                                    ("REINFOCUS_FOCUS_BAND", "64"), ("REINFOCUS_FOCUS_BAND", "5"),
+                                    ("REINFOCUS_FOCUS_KERNEL", "byte"), ("REINFOCUS_FOCUS_KERNEL", "quad")])
+def test_focus_kernels_agree(native, oracle, monkeypatch, switch):
+    """Every band height of focus_kernel_roll (the library picks one by launch size), the byte-per-thread kernel and the
+    round-2 kernel give the same exact sums: variances equal to the last bit, and equal to the oracle's to 1e-12."""
+    base = native.Context(0)
+    monkeypatch.setenv(*switch)
+    other = native.Context(0)
+    try:
+        for n, h, w in FOCUS_SHAPES:
+            if w % 4 or w < 8:
+                continue
+            frames = _focus_frames(n, h, w)
+            want = oracle.focus_values(frames)
+            got = []
+            for c in (base, other):
+                c.upload_frames(frames)
+                got.append(c.focus(n, h, w, 15))
+            assert np.array_equal(got[0], got[1]), (n, h, w)
+            assert np.allclose(got[0], want, rtol=1e-12, atol=1e-12), (n, h, w)
+    finally:
+        base.close()
+        other.close()
+
+
+def test_focus_of_a_wide_render(native, oracle):
+    """FastRenderer.render(1024) scored on the device (vision.py:28-39 over render.py:127-188): the frame sizes the
+    round-5 focus kernels could not take (rows staged whole in 64 KB of LDS)."""
+    from reinfocus_amd import vision
+    from reinfocus_amd.graphics import render
+
+    r = render.FastRenderer(samples_per_pixel=1, device=0)
+    r.update_targets([8.0])
+    r.update_focus_planes([8.0])
+    frames = r.render(1024)
+    got = np.array(vision.focus_values(frames))
+    want = oracle.focus_values(np.asarray(frames))
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    r.close()
 
 
 def test_focus_of_rendered_frames(ctx, oracle):

@@ -40,6 +40,8 @@ def hs():
     lib.hs_check_sky.restype = ctypes.c_long
     lib.hs_check_accept.restype = ctypes.c_long
     lib.hs_check_accept.argtypes = [p, ctypes.c_long, ctypes.c_int, p]
+    lib.hs_variance_from_sums.restype = ctypes.c_double
+    lib.hs_variance_from_sums.argtypes = [ctypes.c_uint64] * 3
     return lib
 
 
@@ -236,3 +238,26 @@ def test_kernel_arithmetic_extreme_scenes(hs, oracle):
         s2 = st0.copy()
         assert np.array_equal(_hs_render(hs, scene, n, h, w, spp, s2, mode), want)
         assert np.array_equal(s2, st)
+
+
+def test_variance_from_sums_is_exact_for_any_pixel_count(hs):
+    """focus_finalize / env_variance (rf_math.h variance_from_sums): (N S2 - S1^2) / N^2 with a 128-bit numerator.  Up to
+    round 5 the numerator was cut to 64 bits: wrong from 3.4e7 pixels on (vision.py:25 scores any image)."""
+    from fractions import Fraction
+
+    rng = np.random.default_rng(11)
+    for npix in (1, 4, 90000, 65536, 600 * 600, 4096 * 4096, 1 << 25, (1 << 26) + 12345, 1 << 31, 40000 * 40000):
+        for _ in range(50):
+            # a population of values in [0, 255]: k pixels of value a, the rest of value b (and all-equal frames)
+            a, b = (int(v) for v in rng.integers(0, 256, size=2))
+            k = int(rng.integers(0, npix + 1))
+            s1 = k * a + (npix - k) * b
+            s2 = k * a * a + (npix - k) * b * b
+            want = Fraction(npix * s2 - s1 * s1, npix * npix)
+            got = hs.hs_variance_from_sums(npix, s1, s2)
+            assert got == pytest.approx(float(want), rel=4e-16, abs=0.0), (npix, a, b, k)
+        assert hs.hs_variance_from_sums(npix, 255 * npix, 255 * 255 * npix) == 0.0
+    # the largest numerator a 2^26-pixel frame can produce (half 0, half 255) does not fit 64 bits
+    n = 1 << 26
+    assert n * (n // 2 * 255 * 255) - (n // 2 * 255) ** 2 >= 1 << 64
+    assert hs.hs_variance_from_sums(n, n // 2 * 255, n // 2 * 255 * 255) == 127.5 ** 2
