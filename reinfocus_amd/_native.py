@@ -349,6 +349,8 @@ class Context:
     # --- device-resident env step ----------------------------------------------------------
     def env_configure(self, cfg):
         self._env_n = cfg.n
+        self._env_k = ctypes.c_int(0)  # (env_step's count of ended environments, and its reference, made once)
+        self._env_k_ref = ctypes.byref(self._env_k)
         _check(self._lib.rf_env_configure(self._h, ctypes.byref(cfg)))
 
     def env_reset(self, states):
@@ -358,16 +360,19 @@ class Context:
         return obs
 
     def env_step(self, actions, pool):
+        # (addresses as plain integers: the ctypes casts of _ptr cost 2 us each, a sixth of a small environment's step)
         n = self._env_n
         actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(n)
         pool = np.ascontiguousarray(pool, dtype=np.float32).reshape(n, 2)
         obs = np.empty((n, 4), dtype=np.float32)
         rewards = np.empty(n, dtype=np.float64)
-        truncated = np.empty(n, dtype=np.uint8)
-        k = ctypes.c_int(0)
-        _check(self._lib.rf_env_step(self._h, _ptr(actions), _ptr(pool), _ptr(obs), _ptr(rewards), _ptr(truncated),
-                                     ctypes.byref(k)))
-        return obs, rewards, truncated.astype(bool), k.value
+        truncated = np.empty(n, dtype=np.bool_)  # (the library writes 0 / 1 bytes)
+        k = self._env_k
+        rc = self._lib.rf_env_step(self._h, actions.ctypes.data, pool.ctypes.data, obs.ctypes.data, rewards.ctypes.data,
+                                   truncated.ctypes.data, self._env_k_ref)
+        if rc != 0:
+            _check(rc)
+        return obs, rewards, truncated, k.value
 
     def env_step_begin(self, actions):
         """First half of a two-phase step: (rewards, truncated, number of environments that ended)."""

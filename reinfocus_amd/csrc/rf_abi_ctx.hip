@@ -192,7 +192,12 @@ int rf_create(int device, rf_ctx **out)
     if (const char *v = getenv("REINFOCUS_RENDER_STRIP"))
         ctx->strip = strcmp(v, "0") != 0;
     if (const char *v = getenv("REINFOCUS_RENDER_SETS"))
+    {
         ctx->auto_form = v[0] != '3'; // (3: three pixels per thread with cooperative tails for launches of every size)
+        if (v[0] == 'w' && v[1] >= '1' && v[1] <= '3')
+            ctx->wave_sets = v[1] - '0';
+        ctx->one_px = v[0] == '1';
+    }
     if (const char *v = getenv("REINFOCUS_GENERAL_DENSE"))
         ctx->general_dense = v[0] != '0', ctx->general_dense_always = v[0] == '1';
     if (const char *v = getenv("REINFOCUS_ENV_FUSED"))

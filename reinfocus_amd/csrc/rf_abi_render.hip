@@ -9,6 +9,7 @@
 #include "rf_coop2.h"
 #include "rf_focus.h"
 #include "rf_render.h"
+#include "rf_wave.h"
 
 using namespace rfh;
 
@@ -96,7 +97,13 @@ int ensure_frames2(rf_ctx *ctx, int n, int h, int w)
 
 int render_form(const rf_ctx *ctx, int n, int h, int w)
 {
-    if (!ctx->coop || (ctx->auto_form && few_blocks((uint64_t)n, (uint64_t)h, (uint64_t)w)))
+    if (!ctx->coop || ctx->one_px)
+        return 0;
+    if (ctx->wave_sets)
+        return 20 + ctx->wave_sets;
+    if (!ctx->auto_form)
+        return 3;
+    if (few_blocks((uint64_t)n, (uint64_t)h, (uint64_t)w))
         return 0;
     return 3;
 }
@@ -193,6 +200,36 @@ int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, c
                     hipLaunchKernelGGL((rf::render_kernel_coop2_strip<0, 2>), tiles_s, block2, 0, ctx->stream, b);
                     ctx->render_kernel = "render_kernel_coop2_strip<0, 2>";
                 }
+            } else if (axis && form > 20) {
+                const int sets = form - 20;
+                const int chunks = (a.hw + 63) / 64; // sets of 64 consecutive pixels; a wave takes `sets` of them
+                const dim3 waves((unsigned)((chunks + sets - 1) / sets), ne);
+#define RF_LAUNCHW_ONE(P, L, K)                                                                            \
+    if (second) {                                                                                          \
+        hipLaunchKernelGGL((rf::render_kernel_wave<P, L, K, true>), waves, dim3(64), 0, ctx->stream, b);    \
+        ctx->render_kernel = "render_kernel_wave<" #P ", " #L ", " #K ", true>";                           \
+    } else {                                                                                               \
+        hipLaunchKernelGGL((rf::render_kernel_wave<P, L, K, false>), waves, dim3(64), 0, ctx->stream, b);   \
+        ctx->render_kernel = "render_kernel_wave<" #P ", " #L ", " #K ", false>";                          \
+    }
+#define RF_LAUNCHW(P, L)                                                                                   \
+    do {                                                                                                   \
+        switch (sets) {                                                                                    \
+        case 1: RF_LAUNCHW_ONE(P, L, 1); break;                                                            \
+        case 2: RF_LAUNCHW_ONE(P, L, 2); break;                                                            \
+        default: RF_LAUNCHW_ONE(P, L, 3); break;                                                           \
+        }                                                                                                  \
+    } while (0)
+                if (pow2 && lens32)
+                    RF_LAUNCHW(true, 1);
+                else if (pow2)
+                    RF_LAUNCHW(true, 0);
+                else if (lens32)
+                    RF_LAUNCHW(false, 1);
+                else
+                    RF_LAUNCHW(false, 0);
+#undef RF_LAUNCHW_ONE
+#undef RF_LAUNCHW
             } else if (axis && form == 3) {
 #define RF_LAUNCH2_ONE(P, L, WX, WW)                                                                       \
     if (second) {                                                                                          \

@@ -46,8 +46,12 @@ struct rf_ctx {
     rf::CamStatic cs{};
     bool axis = false;
     bool coop = true; // cooperative rejection tails (REINFOCUS_RENDER_COOP=0: render_kernel for every launch)
-    bool auto_form = true; // launches of few blocks take the kernel without cooperative tails (few_blocks;
-                           // REINFOCUS_RENDER_SETS=3: three pixels per thread with them at every size)
+    bool auto_form = true; // launches of few blocks take the kernel without cooperative tails, mid-size launches the
+                           // wave-cooperative one (render_form; REINFOCUS_RENDER_SETS=3: three pixels per thread with
+                           // block-cooperative tails for launches of every size)
+    int wave_sets = 0;     // REINFOCUS_RENDER_SETS=w1 / w2 / w3: render_kernel_wave<K> for launches of every size
+                           // (1 ... 3), REINFOCUS_RENDER_SETS=1: render_kernel (0: by launch size)
+    bool one_px = false;
     bool strip = true; // a frame's last w % 64 <= 48 columns as tiles of 48 x 16 (REINFOCUS_RENDER_STRIP=0: one tile shape)
     double hit_fraction = 0.658; // target width / frame width of the current scene (tan 10 / tan 15 deg by default)
     bool general_one = true; // general renderer: cooperative kernel for one-shape worlds (REINFOCUS_GENERAL_ONE=0: never)
@@ -178,8 +182,8 @@ struct SecondPass {
     const int *count;
     const float *cam, *rect;
 };
-// 3 = three pixels per thread with cooperative tails (render_kernel_coop2 and its strip form), 0 = one pixel per
-// thread without them (render_kernel)
+// 3 = three pixels per thread with block-cooperative tails (render_kernel_coop2 and its strip form), 0 = one pixel per
+// thread without them (render_kernel), 20 + K = render_kernel_wave<K> (K pixels per thread, wave-cooperative tails)
 int render_form(const rf_ctx *ctx, int n, int h, int w);
 // enqueues the render of n envs whose scene arrays are cam / rect (device pointers)
 int launch_render(rf_ctx *ctx, int n, int h, int w, int spp, const float *cam, const float *rect, bool axis,

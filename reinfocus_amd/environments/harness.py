@@ -57,6 +57,19 @@ class _Initializer:
     def initialize(self, num_envs):
         return self._generator.uniform(self._ends[0], self._ends[1], size=(num_envs, 2)).astype(np.float32)
 
+    def propose(self, num_envs):
+        """The rows initialize(num_envs) WOULD return, without consuming them: the device-resident step hands row r to the
+        r-th environment that ends and initialize(k) then draws exactly the k rows that were used (same consumption as
+        vector_environment.py:144).  The generator's state is saved and put back -- a deepcopy of the Generator cost 15-65 us
+        per step, a quarter of a small environment's step -- and the rows are low + (high - low) * random(), which is what
+        Generator.uniform computes (tests/test_harness_logic.py compares them bit for bit)."""
+        bit_generator = self._generator.bit_generator
+        state = bit_generator.state
+        lo, hi = self._ends
+        rows = (lo + (hi - lo) * self._generator.random((num_envs, 2))).astype(np.float32)
+        bit_generator.state = state
+        return rows
+
 
 class _Ender:
     """TimeLimitEnder | DivergingEnder (episode_ender.py:580-656, :106-207, :369-452);
@@ -479,12 +492,9 @@ class DeviceVectorDiscreteSteps(_VectorEnvBase):
 
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, frame_height=300,
                  samples_per_pixel=100, seed=None, device=None, first_state_index=0):
-        import copy
-
         super().__init__()
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         self.render_mode = render_mode
-        self._copy = copy
         self.num_envs = num_envs
         self._shard = _DeviceShard(num_envs, max_episode_steps, frame_height, samples_per_pixel, device,
                                    first_state_index)
@@ -514,9 +524,7 @@ class DeviceVectorDiscreteSteps(_VectorEnvBase):
         return observations, {}
 
     def step(self, actions):
-        generator = self._initializer._generator
-        proposal = self._copy.deepcopy(generator)
-        pool = proposal.uniform(self._limits[0], self._limits[1], size=(self.num_envs, 2)).astype(np.float32)
+        pool = self._initializer.propose(self.num_envs)
         observations, rewards, truncated, used = self._ctx.env_step(actions, pool)
         if used:
             self._initializer.initialize(used)  # consume exactly the rows that were used
@@ -612,8 +620,6 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
     def __init__(self, max_episode_steps=20, num_envs=1, render_mode=None, *, devices=None, frame_height=300,
                  samples_per_pixel=100, seed=None, first_state_index=0, exact=False, numa_pin=True):
         import concurrent.futures
-        import copy
-
         from reinfocus_amd import _native
 
         super().__init__()
@@ -624,7 +630,6 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         self.render_mode = render_mode
         self.exact = bool(exact)
         self._last_ended = None  # environments that ended in the last step, per shard (None: after a reset)
-        self._copy = copy
         if devices is None:
             devices = list(range(_native.device_count()))
         devices = [int(d) for d in devices]
@@ -757,8 +762,7 @@ class ShardedVectorDiscreteSteps(_VectorEnvBase):
         # through a step: check all of them before any shard begins
         if actions.size and (actions.min() < 0 or actions.max() >= len(self._action_set)):
             raise AssertionError(f"action outside [0, {len(self._action_set)})")
-        proposal = self._copy.deepcopy(self._initializer._generator)
-        pool = proposal.uniform(self._limits[0], self._limits[1], size=(self.num_envs, 2)).astype(np.float32)
+        pool = self._initializer.propose(self.num_envs)
         firsts = self._begin(actions)
         ended = [k for _, _, k in firsts]
         starts = np.concatenate([[0], np.cumsum(ended)]).astype(int)

@@ -152,3 +152,27 @@ def test_continuous_jumps_arithmetic(env):
     assert abs(cj._state[0, 1] - 7.0) < 1e-6
     obs, reward, *_ = cj.step(np.float32(-0.21))
     assert abs(cj._state[0, 1] - 7.0) < 1e-6 and reward == np.float64(obs[1]) + 1.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345])
+@pytest.mark.parametrize("n", [1, 8, 257])
+def test_proposed_rows_are_the_rows_the_initializer_draws(seed, n):
+    """_Initializer.propose (the device-resident step's candidate rows) returns what initialize would, bit for bit, and
+    consumes nothing: state_initializer.py:30-71 draws with Generator.uniform, vector_environment.py:144 only for the
+    environments that ended."""
+    from reinfocus_amd.environments import harness
+
+    ends = harness._DeviceShard.ENDS
+    a, b = harness._Initializer(ends, seed), harness._Initializer(ends, seed)
+    for _ in range(5):
+        rows = a.propose(n)
+        assert rows.dtype == np.float32 and rows.shape == (n, 2)
+        assert np.array_equal(rows, a.propose(n))  # nothing consumed
+        used = int(np.random.default_rng(seed + n).integers(0, n + 1))
+        want = b.initialize(n if used == 0 else used)
+        if used:
+            assert np.array_equal(a.initialize(used), want)
+            assert np.array_equal(rows[:used], want)
+        else:
+            assert np.array_equal(rows, want)
+            a.initialize(n)
