@@ -80,34 +80,84 @@ void drop_env_graph(rf_ctx *ctx)
     ctx->env_steps = 0;
 }
 
-// Splits the lens radius for rf_math.h lens_offset and decides -- by trying every float32 a disc
-// coordinate can be (multiples of 2^-24 in [-1, 0), of 2^-23 in [0, 1]) -- whether the float32
-// form reproduces float32(float64(p) * radius) for this radius.  ~60 ms on one core; remembered
-// per radius for the life of the process (the reference's FastCameras always uses 0.05).
+// Whether the float32 form of rf_math.h lens_offset reproduces float32(float64(p) * radius) for EVERY float32 p a disc
+// coordinate can be (multiples of 2^-24 in [-1, 0), of 2^-23 in [0, 1]): tried one by one, ~60 ms on one core.
+static bool lens_f32_exact(double radius, float hi, float lo)
+{
+    bool exact = true;
+    for (int k = 0; exact && k <= (1 << 24); ++k) {
+        const float neg = (float)((double)k * (1.0 / 16777216.0) - 1.0); // k 2^-24 - 1, exact
+        const float pos = (float)((double)k * (1.0 / 8388608.0));          // k 2^-23 (k <= 2^23)
+        exact = fmaf(neg, hi, neg * lo) == (float)((double)neg * radius) &&
+                (k > (1 << 23) || fmaf(pos, hi, pos * lo) == (float)((double)pos * radius));
+    }
+    return exact;
+}
+
+// What the process knows about lens radii.  The reference's aperture 0.1 (camera.py:106: FastCameras and make_gpu_camera's
+// default) is entered as proven -- tests/test_hostsim.py::test_lens_offset_float32_form runs the proof on the same
+// arithmetic -- so that no process pays for it; everything else is proven on demand, OUTSIDE the lock (two threads may prove the
+// same radius at the same time: same answer), so that contexts on other threads never wait 60 ms for a mutex.
+namespace {
+struct LensRecord {
+    int exact = -1;    // -1: not proven yet
+    unsigned asked = 0; // calls of the general renderer that would have liked to know
+};
+std::mutex lens_guard;
+std::map<double, LensRecord> lens_known = {{0.05, LensRecord{1, 0}}};
+} // namespace
+
+// Splits the lens radius for rf_math.h lens_offset and decides whether the float32 form is exact for it (the fast path's
+// question: ONE radius per context, used by every sample of every render -- always worth the proof).  Remembered per radius
+// for the life of the process.
 void lens_split(rf::CamStatic &cs)
 {
-    static std::mutex guard;
-    static std::map<double, bool> known;
     const double radius = cs.lens_radius;
     cs.lens_hi = (float)radius;
     cs.lens_lo = (float)(radius - (double)cs.lens_hi);
     cs.lens_f32 = 0;
     if (!(radius == radius) || radius - radius != 0.0) // NaN / infinity: literal path
         return;
-    std::lock_guard<std::mutex> lock(guard);
-    auto it = known.find(radius);
-    if (it == known.end()) {
-        bool exact = true;
-        const float hi = cs.lens_hi, lo = cs.lens_lo;
-        for (int k = 0; exact && k <= (1 << 24); ++k) {
-            const float neg = (float)((double)k * (1.0 / 16777216.0) - 1.0); // k 2^-24 - 1, exact
-            const float pos = (float)((double)k * (1.0 / 8388608.0));          // k 2^-23 (k <= 2^23)
-            exact = fmaf(neg, hi, neg * lo) == (float)((double)neg * radius) &&
-                    (k > (1 << 23) || fmaf(pos, hi, pos * lo) == (float)((double)pos * radius));
+    {
+        std::lock_guard<std::mutex> lock(lens_guard);
+        auto it = lens_known.find(radius);
+        if (it != lens_known.end() && it->second.exact >= 0) {
+            cs.lens_f32 = it->second.exact;
+            return;
         }
-        it = known.emplace(radius, exact).first;
     }
-    cs.lens_f32 = it->second ? 1 : 0;
+    const bool exact = lens_f32_exact(radius, cs.lens_hi, cs.lens_lo);
+    std::lock_guard<std::mutex> lock(lens_guard);
+    lens_known[radius].exact = exact ? 1 : 0;
+    cs.lens_f32 = exact ? 1 : 0;
+}
+
+// The general renderer's question (rf_render_general, per camera of a launch): is the float32 lens offset KNOWN to be exact
+// for this radius?  Its SIMPLE kernel instances are ~3 % faster than the ones with the reference's float64 lens products --
+// of a render of about a millisecond -- and a proof costs 60 ms, so a radius is only proven once it has come back in
+// kLensProveAfter calls (an aperture sweep, one new radius per call, never pays; REINFOCUS_LENS_PROVE_AFTER=n changes the
+// count, tests set 1).  Until then: false, the float64 instances -- the same frames either way.
+bool lens_exact_if_known(double radius)
+{
+    static const unsigned prove_after = [] {
+        const char *v = getenv("REINFOCUS_LENS_PROVE_AFTER");
+        const long n = v ? strtol(v, nullptr, 10) : 0;
+        return (unsigned)(n >= 1 ? n : 64);
+    }();
+    if (!(radius == radius) || radius - radius != 0.0)
+        return false;
+    {
+        std::lock_guard<std::mutex> lock(lens_guard);
+        LensRecord &record = lens_known[radius];
+        if (record.exact >= 0)
+            return record.exact == 1;
+        if (++record.asked < prove_after)
+            return false;
+    }
+    rf::CamStatic probe{};
+    probe.lens_radius = radius;
+    lens_split(probe);
+    return probe.lens_f32 != 0;
 }
 
 int seed_range(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t seed, uint64_t first_state_index)

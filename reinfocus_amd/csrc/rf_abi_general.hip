@@ -8,26 +8,29 @@
 #include <set>
 #include <vector>
 
+#include "rf_general_chunk.h"
 #include "rf_general_one.h"
 
 using namespace rfh;
 
 namespace {
 
-// make_random_states(n, seed 0) for rf_render_general: the jump-ahead seeding the first time a size is
-// asked for, a device-to-device copy of the remembered result afterwards (same bytes; sizes above
-// 4 GiB of states are seeded every time rather than remembered)
-int seed_zero_cached(rf_ctx *ctx, uint64_t n_states)
+// make_random_states(n, seed 0) for rf_render_general: the jump-ahead seeding the first time a size is asked for, with a
+// copy of the result kept; afterwards the kernels read their pixels' states straight from that copy (GeneralArgs::states_in)
+// and write the advanced ones to the context's array -- no copy per call (round 5 copied 32 bytes per pixel in front of
+// every render: 0.1 of 3.47 ms at 256 x 256^2 x 16).  Sizes above 4 GiB of states are seeded every time rather than remembered.
+// *states_in: where this call's start states are.
+int seed_zero_cached(rf_ctx *ctx, uint64_t n_states, const ulonglong2 **states_in)
 {
     constexpr uint64_t kMaxCachedStates = (4ull << 30) / sizeof(ulonglong2);
     if (ctx->d_seed_cache && ctx->seed_cache_n == n_states && ctx->n_states == n_states) {
         RF_HIP(hipSetDevice(ctx->device));
         drop_env_graph(ctx);
-        RF_HIP(hipMemcpyAsync(ctx->d_states, ctx->d_seed_cache, n_states * sizeof(ulonglong2), hipMemcpyDeviceToDevice,
-                              ctx->stream));
+        *states_in = ctx->d_seed_cache;
         return RF_OK;
     }
     int rc = rf_seed(ctx, n_states, 0, 0);
+    *states_in = ctx->d_states;
     if (rc != RF_OK || n_states > kMaxCachedStates)
         return rc;
     if (ctx->seed_cache_n != n_states) {
@@ -69,7 +72,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                        "rf_render_general: unknown shape type");
     }
     const uint64_t hw64 = (uint64_t)h * (uint64_t)w, pixels = (uint64_t)n * hw64;
-    int rc = seed_zero_cached(ctx, pixels); // render.py:115: fresh seed-0 states per call
+    const ulonglong2 *states_in = nullptr;
+    int rc = seed_zero_cached(ctx, pixels, &states_in); // render.py:115: fresh seed-0 states per call
     if (rc != RF_OK)
         return rc;
     rc = ensure_frames(ctx, n, h, w);
@@ -103,9 +107,10 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                      (ctx->general_one_always || pixels > (one_sphere ? 3000000u : 2000000u));
     for (int e = 0; one_shape && e < n; ++e)
         one_shape = types[(size_t)e] == (one_sphere ? 0 : 1);
-    // every camera: canonical axes (cheap, first) and a lens radius whose float32 offset is proven exact -- a proof costs
-    // ~60 ms of host time once per radius and process (lens_split), so a launch with more than a handful of different
-    // apertures is not worth it: it takes the instances with the reference's float64 lens products
+    // every camera: canonical axes (cheap, first) and a lens radius whose float32 offset is KNOWN to be exact -- the
+    // reference's aperture, or a radius that has come back often enough to have been worth its 60 ms proof
+    // (rf_abi_ctx.hip lens_exact_if_known); a launch with more than a handful of different apertures takes the instances
+    // with the reference's float64 lens products right away
     auto cameras_simple = [&]() {
         std::set<double> radii;
         for (int e = 0; e < n; ++e) {
@@ -116,14 +121,10 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             if (radii.size() > 4)
                 return false;
         }
-        for (const double radius : radii) {
-            rf::CamStatic probe{};
-            probe.lens_radius = radius;
-            lens_split(probe); // (remembered per radius)
-            if (probe.lens_f32 == 0)
-                return false;
-        }
-        return true;
+        bool all = true;
+        for (const double radius : radii) // (every radius is asked about: each counts its calls)
+            all = lens_exact_if_known(radius) && all;
+        return all;
     };
     if (one_shape) {
         kind = kOne;
@@ -134,8 +135,12 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     }
     const bool listed = kind != kLiteral;
 
-    // environments per launch: the grid's y limit, and (kernels with a fix-up list) pixel indices in 32 bits
-    const int chunk = listed ? (int)std::min<uint64_t>(65535, 0xFFFFFFFFull / hw64) : 65535;
+    // environments per launch: the grid's y limit, and (kernels with a fix-up list: one-dimensional grids) pixel indices and
+    // launched threads in 32 bits (rf_general_chunk.h)
+    bool tiled = false, narrow = false;
+    const uint64_t per_env = kind == kDense ? rf::dense_blocks_per_env(h, w, &tiled)
+                             : kind == kOne ? rf::one_blocks_per_env(h, w, rf::kSets, &narrow) : 0;
+    const int chunk = listed ? rf::general_listed_chunk(hw64, per_env) : 65535;
     const int n_chunks = (n + chunk - 1) / chunk;
     // the fix-up list: about one pixel in 10^3 abstains (one in 10^2 at 100 samples); a launch that abstains more often
     // than the list holds is rendered again by the literal kernel (below)
@@ -182,6 +187,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
     rf::GeneralArgs a;
     a.frames = ctx->d_frames;
     a.states = ctx->d_states;
+    a.states_in = states_in;
     a.cameras = (const rf::GeneralCamera *)scratch;
     a.params = (const float *)(scratch + o_par);
     a.types = (const int32_t *)(scratch + o_typ);
@@ -200,6 +206,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
         rf::GeneralArgs b = a;
         b.frames = a.frames + (size_t)e0 * a.hw * 3;
         b.states = a.states + (size_t)e0 * a.hw;
+        b.states_in = a.states_in + (size_t)e0 * a.hw;
         b.cameras = a.cameras + (size_t)e0;
         b.params = a.params + (size_t)e0 * most * width;
         b.types = a.types + (size_t)e0 * most;
@@ -237,10 +244,7 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
             if (kind == kDense) {
                 // 16 x 16 tiles (waves of 8 x 8 pixels) unless they pad the frame much more than 256-pixel runs do (frames
                 // narrower or lower than a tile)
-                const uint64_t tiles = (uint64_t)((w + 15) / 16) * (uint64_t)((h + 15) / 16);
-                const bool tiled = tiles * 256 * 100 <= (uint64_t)gx * 256 * 115;
-                const uint64_t per_env = tiled ? tiles : (uint64_t)gx;
-                RF_REQUIRE(per_env * (uint64_t)ne < (1ull << 31), "rf_render_general: too many blocks for one launch");
+                RF_REQUIRE(per_env * (uint64_t)ne * 256 <= 0xFFFFFFFFull, "rf_render_general: too many threads for one launch");
                 const dim3 grid_t((unsigned)(per_env * (uint64_t)ne)); // (the environment is the fastest index)
 #define RF_LAUNCH_DENSE_TS(P, NS, T, S)                                                                                   \
     do {                                                                                                               \
@@ -266,10 +270,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                 continue;
             }
             // tiles of 128 x 6 or of 64 x 12, whichever leaves fewer dead columns
-            const bool narrow = ((w + 63) / 64) * 64 < ((w + 127) / 128) * 128;
-            const uint64_t tiles_one = narrow ? (uint64_t)((w + 63) / 64) * (uint64_t)((h + 4 * rf::kSets - 1) / (4 * rf::kSets))
-                                              : (uint64_t)((w + 127) / 128) * (uint64_t)((h + 2 * rf::kSets - 1) / (2 * rf::kSets));
-            const dim3 tiles((unsigned)(tiles_one * (uint64_t)ne)); // (one-dimensional, the environment fastest)
+            RF_REQUIRE(per_env * (uint64_t)ne * 256 <= 0xFFFFFFFFull, "rf_render_general: too many threads for one launch");
+            const dim3 tiles((unsigned)(per_env * (uint64_t)ne)); // (one-dimensional, the environment fastest)
 #define RF_LAUNCH_ONE(P, S, WXV)                                                                                          \
     do {                                                                                                               \
         hipLaunchKernelGGL((rf::render_general_one_kernel<P, S, WXV>), tiles, dim3(rf::kBlock2), 0, ctx->stream, d);   \
@@ -287,6 +289,8 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
 #undef RF_LAUNCH_ONE
         }
         RF_HIP(hipGetLastError());
+    } // (the events close here: around the kernels, not around the read-back of the counts and its synchronisation)
+    {
         ctx->general_redo_last = 0;
         if (listed) {
             // how many pixels abstained, per launch; a launch with more of them than the list holds is rendered again, whole,
@@ -304,7 +308,9 @@ int rf_render_general(rf_ctx *ctx, int n, int h, int w, int spp, const double *c
                 rc = seed_range(ctx, first, count, 0, first); // (the jump-ahead kernel, not the remembered copy: one path, rarely taken)
                 if (rc != RF_OK)
                     return rc;
-                launch_literal(chunk_args(e0, ne));
+                rf::GeneralArgs again = chunk_args(e0, ne);
+                again.states_in = again.states; // (freshly seeded in place)
+                launch_literal(again);
                 RF_HIP(hipGetLastError());
             }
             ctx->general_redo_last = (unsigned)std::min<unsigned long long>(redo, 0xFFFFFFFFull);

@@ -50,15 +50,22 @@ int pick_tile_layout(int h, int w, double hit_fraction)
     return best;
 }
 
-// Launches of few blocks -- the reference's own default is ONE environment of 300 x 300 pixels at 100 samples: 119
-// blocks of three pixels per thread on 256 CUs, each running its samples one after the other -- are bound by the
-// latency of a sample, not by issue slots: with one or two waves per SIMD nothing hides the cooperative tails' barriers,
-// and the kernel without them (render_kernel<AXIS, POW2>: one pixel per thread, rejection loops inside the wave) is the
-// fastest form -- 1 x 300^2 x 100: 687 us per step with three pixels per thread, 419 with one and cooperative tails, 289
-// without them; 4 environments 863 / 646 / 563.  Three pixels per thread win from about 650 000 pixels per launch on (10
-// environments of 300^2 or of 256^2, 40 of 128^2: profiles/r04_ab.txt section 18), at any number of samples (the
-// kernel has a two-pass form of its own, so the fused step's few launches serve both).
-bool few_blocks(uint64_t n, uint64_t h, uint64_t w) { return n * h * w <= 650000; }
+// Which of the three organisations a launch of the canonical camera takes, by its pixels (all bit-identical; round 6,
+// fused step, us per env step of in-wave / wave-cooperative / block-cooperative: profiles/r06_ab.txt section 3):
+//   * few blocks -- the reference's own default is ONE environment of 300 x 300 pixels at 100 samples
+//     (gym.make("DiscreteSteps-v0")) -- are bound by the latency of a sample: render_kernel<AXIS, POW2>, one pixel per
+//     thread, rejection loops inside the wave, nothing to wait for (1 x 300^2 x 100: 253 us per step against 688 for
+//     three pixels per thread with block-cooperative tails; 4: 501 / 575 / 832; 5: 570 / 642 / 910).
+//   * launches that are about ONE round of resident waves -- the reference's training shape, 8 environments of 300^2 at
+//     100 samples (examples/ppo_tuned.yml:5): 3752 waves on 1024 SIMDs -- are bound by vector issue at 3-4 waves per
+//     SIMD, where nothing hides a block barrier: render_kernel_wave<.., 3> (rf_wave.h; 6 x 300^2 x 100: 703 / 661 / 954,
+//     8: 876 / 757 / 1046, 16: 1519 / 1305 / 1317, 24: 2150 / 1753 / 1809; 16 x 256^2 x 16: 230 / 212 / 222;
+//     128 x 128^2 x 4: 159 / 126 / 128; 4 x 512^2 x 64: 722 / 650 / 653).
+//   * from about two rounds on, three pixels per thread with block-cooperative tails (render_kernel_coop2 and its strip
+//     form; 48 x 256^2 x 16: 536 / 430 / 416, 256 x 128^2 x 4: 254 / 188 / 187).
+constexpr uint64_t kFewPixels = 500000, kOneRoundPixels = 2200000;
+bool few_blocks(uint64_t n, uint64_t h, uint64_t w) { return n * h * w <= kFewPixels; }
+bool one_round(uint64_t n, uint64_t h, uint64_t w) { return n * h * w <= kOneRoundPixels; }
 
 } // namespace
 
@@ -105,6 +112,8 @@ int render_form(const rf_ctx *ctx, int n, int h, int w)
         return 3;
     if (few_blocks((uint64_t)n, (uint64_t)h, (uint64_t)w))
         return 0;
+    if (one_round((uint64_t)n, (uint64_t)h, (uint64_t)w))
+        return 23;
     return 3;
 }
 

@@ -18,6 +18,11 @@ namespace rf {
 struct GeneralArgs {
     uint8_t *frames;
     ulonglong2 *states;
+    // where a pixel's state is read from: `states` itself, or the context's copy of the freshly seeded array -- every call
+    // of the general renderer starts from seed-0 states (render.py:115), and reading them from the copy saves the call a
+    // device-to-device copy of 32 bytes per pixel in front of the kernel.  A pixel that abstains writes nothing, and the
+    // fix-up kernel reads its state from here as well.
+    const ulonglong2 *states_in;
     const GeneralCamera *cameras; // [n], cast from float64[n][19] on the host
     const float *params;    // [n][most][width]
     const int32_t *types;   // [n][most]
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(kBlock, kGeneralOcc) void render_general_kernel(Gen
     uint8_t r8 = 0, g8 = 0, b8 = 0;
     if (live) {
         const int y = p / a.w, x = p - y * a.w;
-        const ulonglong2 st = a.states[pix];
+        const ulonglong2 st = a.states_in[pix];
         Rng g = rng_load(st.x, st.y);
         float cr, cg, cb;
         render_pixel_general<POW2>(g, x, y, a.h, a.w, a.spp, a.cameras[e],

@@ -140,7 +140,7 @@ render_general_one_kernel(GeneralOneArgs ra)
         const Geometry g0 = geometry(tid);
         g[j] = rng_load(0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull); // dead lanes: any state
         if (g0.live_of(j)) {
-            const ulonglong2 st = a.states[pix_of(g0, j)];
+            const ulonglong2 st = a.states_in[pix_of(g0, j)];
             g[j] = rng_load(st.x, st.y);
         }
     }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void render_general_fixup_kernel(GeneralOne
         const unsigned pix = ra.redo_list[i];
         const int e = (int)(pix / (unsigned)a.hw), p = (int)(pix - (unsigned)e * (unsigned)a.hw);
         const int y = p / a.w, x = p - y * a.w;
-        const ulonglong2 st = a.states[pix];
+        const ulonglong2 st = a.states_in[pix];
         Rng g = rng_load(st.x, st.y);
         float cr, cg, cb;
         render_pixel_general<POW2>(g, x, y, a.h, a.w, a.spp, a.cameras[e], a.params + ((size_t)e * a.most) * a.width,
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kBlock, kDenseOcc) void render_general_dense_kernel
     const size_t pix = (size_t)e * a.hw + (live ? (size_t)y * a.w + x : 0);
     uint8_t r8 = 0, g8 = 0, b8 = 0;
     if (live) {
-        const ulonglong2 st = a.states[pix];
+        const ulonglong2 st = a.states_in[pix];
         Rng g = rng_load(st.x, st.y);
         const_as<GeneralCamera> &cam = *as_const(a.cameras + e);
         const_as<ShapeConst> *const sc = as_const(ra.shapes + (size_t)e * NS);

@@ -173,6 +173,8 @@ int seed_range(rf_ctx *ctx, uint64_t first, uint64_t count, uint64_t seed, uint6
 
 // Splits the lens radius for rf_math.h lens_offset and decides whether the float32 form is exact for it
 void lens_split(rf::CamStatic &cs);
+// ... the same question without the 60 ms proof for a radius the process has seen in fewer than 64 calls (rf_render_general)
+bool lens_exact_if_known(double radius);
 
 int ensure_frames(rf_ctx *ctx, int n, int h, int w);
 int ensure_frames2(rf_ctx *ctx, int n, int h, int w);

@@ -25,16 +25,16 @@
 namespace rf {
 
 #ifndef RF_WAVE_OCC
-#define RF_WAVE_OCC 7
+#define RF_WAVE_OCC 4
 #endif
 #ifndef RF_WAVE_COLOUR_LDS
-#define RF_WAVE_COLOUR_LDS 2
+#define RF_WAVE_COLOUR_LDS 0
 #endif
 #ifndef RF_WAVE_XY_LDS
-#define RF_WAVE_XY_LDS 1
+#define RF_WAVE_XY_LDS 0
 #endif
 #ifndef RF_WAVE_STATE_OUT
-#define RF_WAVE_STATE_OUT 0
+#define RF_WAVE_STATE_OUT 1
 #endif
 #ifndef RF_WAVE_PRIO
 #define RF_WAVE_PRIO 0
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64, WaveTune<K>::occupancy) void render_kernel_wave
     // Set j of wave b = the 64 pixels from (b + j B) * 64 on, B = gridDim.x: a wave's K sets lie a K-th of the frame apart.
     // Rows that cross the (centred) target cost 2.5x the rows above and below it (the whole sphere phase), and a launch of
     // this size is ONE round of resident waves: with consecutive sets a SIMD's load would be whatever mix of cheap and
-    // expensive waves it was dealt (8 x 300^2 x 100: 727 us against ... with every wave a like mix of both).
+    // expensive waves it was dealt (8 x 300^2 x 100: 770 us per launch against 655 with every wave a like mix of both).
     const int chunks_b = (int)gridDim.x;
     auto pixel_of = [&](int t, int j) { return (block_x + j * chunks_b) * 64 + t; };
     Rng g[K];

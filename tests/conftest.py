@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock performance floors on a real MI355X (tests/test_gpu_perf_guard.py; "
+                            "run alone with -m perf: a noisy box must not abort the parity suite)")
     # The library renders launches of few blocks with its kernel without cooperative tails (rf_abi_render.hip few_blocks) --
     # which is most of what tests render.  The tests are there for the benchmarked kernel: three pixels per thread at every size, unless a
     # test asks otherwise (tests/test_gpu_parity.py::test_few_blocks_take_one_pixel_per_thread and the notebook outputs
@@ -25,6 +27,10 @@ def pytest_configure(config):
     # depends on what fresh or recycled memory holds -- a list not cleared, a sum not zeroed -- fails here instead of in a
     # long-lived process (smoke() and bench.py run without it)
     os.environ.setdefault("REINFOCUS_POISON_ALLOC", "1")
+    # the general renderer proves a lens radius it does not know (60 ms on the host) only once it has come back in 64 calls
+    # (rf_abi_ctx.hip lens_exact_if_known); the tests want the float32-lens kernel instances from the first call on
+    # (tests/test_gpu_general.py::test_an_unknown_lens_radius_is_not_proven_at_once runs the library's own count)
+    os.environ.setdefault("REINFOCUS_LENS_PROVE_AFTER", "1")
 
 
 def pytest_sessionstart(session):
@@ -64,17 +70,20 @@ def shipped_libraries_match_their_sources():
     yield
 
 
-@pytest.fixture(params=["three pixels per thread", "the library's choice"])
+@pytest.fixture(params=["three pixels per thread", "the library's choice", "wave-cooperative"])
 def kernel_choice(request, monkeypatch):
     """The render kernels a context created inside the test takes.  The session's default forces the benchmarked kernels at
-    every size (pytest_configure above); a test that names this fixture runs twice -- once like that, once with the
+    every size (pytest_configure above); a test that names this fixture runs three times -- like that; with the
     switches unset, i.e. with the kernels the library itself picks for the launch (for most test sizes: render_kernel
-    without cooperative tails, and the dense or literal general kernel) -- which is what the reference's default use
-    takes (state_observer.py:335: one 300 x 300 environment; examples/ppo_tuned.yml:5: n_envs 8)."""
+    without cooperative tails, and the dense or literal general kernel), which is what the reference's default use takes
+    (state_observer.py:335: one 300 x 300 environment); and with render_kernel_wave<.., 3> forced at every size (rf_wave.h:
+    the library's choice for launches of 0.5-2.2 M pixels -- examples/ppo_tuned.yml:5: n_envs 8 -- which few tests are)."""
     if request.param == "the library's choice":
         monkeypatch.delenv("REINFOCUS_RENDER_SETS", raising=False)
         monkeypatch.delenv("REINFOCUS_GENERAL_ONE", raising=False)
         monkeypatch.delenv("REINFOCUS_GENERAL_DENSE", raising=False)
+    elif request.param == "wave-cooperative":
+        monkeypatch.setenv("REINFOCUS_RENDER_SETS", "w3")
     return request.param
 
 

@@ -12,6 +12,7 @@
 #include "../../reinfocus_amd/csrc/rf_jump.h"
 #include "../../reinfocus_amd/csrc/rf_general.h"
 #include "../../reinfocus_amd/csrc/rf_general_dense.h"
+#include "../../reinfocus_amd/csrc/rf_general_chunk.h"
 #include "../gpucheck/probe_general.h"
 
 using namespace rf;
@@ -511,6 +512,15 @@ int hs_probe_checker(const float *f, const float *u, int *sign, uint64_t n)
     for (uint64_t i = 0; i < n; ++i)
         sign[i] = rf::checker_sign_general(f[i], u[i]);
     return 0;
+}
+
+// rf_render_general's environments per launch of its listed kernels (rf_general_chunk.h): kind 1 = one-shape, 2 = dense
+int hs_general_chunk(int kind, int h, int w, unsigned long long *blocks_per_env)
+{
+    bool flag = false;
+    const uint64_t per_env = kind == 2 ? dense_blocks_per_env(h, w, &flag) : one_blocks_per_env(h, w, 3, &flag);
+    *blocks_per_env = per_env;
+    return general_listed_chunk((uint64_t)h * (uint64_t)w, per_env);
 }
 
 // focus_finalize / env_variance: the variance from the exact integer sums (rf_math.h variance_from_sums)

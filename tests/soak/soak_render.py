@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (not collected by pytest): randomised parity soak of the render + focus path
-against the CPU oracle.  usage (GPU box, repo root): python tests/soak_render.py [cases] [seed]"""
+against the CPU oracle.  usage (GPU box, repo root): python tests/soak/soak_render.py [cases] [seed]"""
 import sys
 import time
 

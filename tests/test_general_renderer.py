@@ -466,3 +466,30 @@ def test_dense_kernel_arithmetic_equals_oracle_wherever_it_does_not_abstain(orac
         assert np.array_equal(s2.reshape(n, h, w, 2)[~keep], st0.reshape(n, h, w, 2)[~keep])
         assert gave_up.mean() < 0.0005 * spp + 0.002, gave_up.mean()  # (about 1e-4 per sample; spheres around the camera more)
     assert len(np.unique(want)) > 20
+
+
+def test_environments_per_launch_keep_threads_and_pixels_in_32_bits():
+    """rf_render_general's listed kernels run on one-dimensional grids of blocks_per_env * ne blocks of 256 threads
+    (rf_general_chunk.h): a launch may hold neither more than 2^32 - 1 pixels (the fix-up list's indices) nor more than
+    2^32 - 1 THREADS -- HIP rejects such a launch, and padded tiles launch up to 15 % more threads than the frame has
+    pixels (round 5 bounded only the pixels: 300 x 300 frames gave chunks of 47 721 environments = 4.41e9 threads)."""
+    import ctypes
+
+    lib = ctypes.CDLL(helpers.built("tests/hostsim", "libhostsim.so"))
+    lib.hs_general_chunk.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]
+    limit = (1 << 32) - 1
+    rng = np.random.default_rng(3)
+    shapes = [(300, 300), (256, 256), (16, 16), (1, 1), (7, 9), (4096, 4096), (97, 129), (600, 600), (128, 128), (1, 4000)]
+    shapes += [(int(a), int(b)) for a, b in rng.integers(1, 4097, size=(300, 2))]
+    for h, w in shapes:
+        for kind in (1, 2):
+            per_env = ctypes.c_ulonglong(0)
+            chunk = lib.hs_general_chunk(kind, h, w, ctypes.byref(per_env))
+            assert 1 <= chunk <= 65535
+            assert chunk * h * w <= limit or chunk == 1, (h, w, kind)
+            assert chunk * per_env.value * 256 <= limit, (h, w, kind)
+            assert per_env.value * 256 * (3 if kind == 1 else 1) >= h * w  # every pixel has a thread (one-shape: three per thread)
+            # ... and no smaller than it has to be
+            assert chunk == 65535 or (chunk + 1) * h * w > limit or (chunk + 1) * per_env.value * 256 > limit, (h, w, kind)
+    per_env = ctypes.c_ulonglong(0)
+    assert lib.hs_general_chunk(2, 300, 300, ctypes.byref(per_env)) == limit // (361 * 256) and per_env.value == 361

@@ -558,3 +558,44 @@ def test_sphere_checker_fast_path_on_the_device():
     assert gc.gc_probe_sphere_red(ptr(normals), ptr(fu), ptr(fv), ptr(device), ctypes.c_uint64(n)) == 0
     hs.hs_probe_sphere_red(1, ptr(normals), ptr(fu), ptr(fv), ptr(reference), ctypes.c_uint64(n))
     assert np.array_equal(device, reference)
+
+
+def test_an_unknown_lens_radius_is_not_proven_at_once(oracle, tmp_path):
+    """The float32 lens offset of the dense kernel's SIMPLE instances needs a 60 ms proof per radius on the host
+    (rf_abi_ctx.hip lens_exact_if_known) -- for a render of about a millisecond that is 3 % faster with it.  So a radius
+    the process does not know takes the instances with the reference's float64 lens products until it has come back
+    (REINFOCUS_LENS_PROVE_AFTER calls: 3 here, 64 by default); the reference's own aperture 0.1 is known from the start.
+    The oracle's frames every time."""
+    import subprocess
+    import sys
+
+    from reinfocus_amd.graphics import camera, shape_factory as sf, world
+
+    two = sf.two_sphere(sf.ShapeParameters(12.0), sf.ShapeParameters(6.0))
+    params, types, sizes = world.Worlds(two, two).device_data()
+    cams = {"known": camera.Cameras(camera.make_gpu_camera(), camera.make_gpu_camera()).device_data(),
+            "new": camera.Cameras(camera.make_gpu_camera(aperture=0.14), camera.make_gpu_camera(aperture=0.14)).device_data()}
+    np.savez(tmp_path / "scene.npz", params=params, types=types, sizes=sizes, **cams)
+    out = tmp_path / "out.npz"
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from reinfocus_amd import _native\n"
+        "d = np.load(%r)\n"
+        "c = _native.Context(0)\n"
+        "names, frames = [], []\n"
+        "for which in ('known', 'new', 'new', 'new', 'new'):\n"
+        "    frames.append(c.render_general(d[which], d['params'], d['types'], d['sizes'], 24, 24, 3))\n"
+        "    names.append(c.render_kernel_name())\n"
+        "np.savez(%r, frames=np.stack(frames), names=np.array(names))\n"
+        "c.close()\n"
+    ) % (helpers.ROOT, str(tmp_path / "scene.npz"), str(out))
+    subprocess.check_call([sys.executable, "-c", script], env=dict(os.environ, REINFOCUS_LENS_PROVE_AFTER="3"))
+    got = np.load(out)
+    names = [str(name) for name in got["names"]]
+    assert all(name.startswith("render_general_dense_kernel<false, 2") for name in names), names
+    assert [name.endswith(", true>") for name in names] == [True, False, False, True, True], names
+    for i, which in enumerate(("known", "new", "new", "new", "new")):
+        st = oracle.seed_states(2 * 24 * 24, 0)
+        want = oracle.render_general(cams[which], params, types, sizes, 24, 24, 3, st, n_threads=4)
+        assert np.array_equal(got["frames"][i], want), (i, names[i])

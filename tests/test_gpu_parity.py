@@ -520,23 +520,45 @@ def test_delayed_waves_change_nothing(oracle, tmp_path, h):
     assert np.array_equal(final, states)
 
 
-@pytest.mark.parametrize("n,h,spp,three", [(1, 300, 8, False), (7, 300, 8, False), (8, 300, 8, True), (9, 256, 9, False), (10, 256, 8, True),
-                                           (2, 128, 3, False), (45, 128, 2, True), (36, 128, 16, False)])
-def test_few_blocks_take_one_pixel_per_thread(oracle, tmp_path, n, h, spp, three):
-    """Without REINFOCUS_RENDER_SETS the library picks the kernel by the size of the launch: up to 650 000 pixels (about
-    850 blocks of three pixels per thread) -- the reference's own default, one environment
-    of 300 x 300 at 100 samples, is such a launch -- render with the kernel without cooperative tails (render_kernel: one
-    pixel per thread, no barriers: such launches are bound by a sample's latency), everything else with three pixels per
-    thread.  Same frames, same RNG states, either way."""
+@pytest.mark.parametrize("n,h,spp,form", [(1, 300, 8, "render_kernel<"), (5, 300, 8, "render_kernel<"), (6, 300, 4, "render_kernel_wave<"),
+                                          (8, 300, 8, "render_kernel_wave<"), (24, 300, 2, "render_kernel_wave<"),
+                                          (25, 300, 2, "render_kernel_coop2"), (7, 256, 9, "render_kernel<"),
+                                          (8, 256, 8, "render_kernel_wave<"), (33, 256, 2, "render_kernel_wave<"),
+                                          (34, 256, 2, "render_kernel_coop2"), (2, 128, 3, "render_kernel<"),
+                                          (30, 128, 16, "render_kernel<"), (31, 128, 4, "render_kernel_wave<"),
+                                          (135, 128, 2, "render_kernel_coop2")])
+def test_the_library_picks_the_kernel_by_launch_size(oracle, tmp_path, n, h, spp, form):
+    """Without REINFOCUS_RENDER_SETS the library picks the kernel by the pixels of the launch (rf_abi_render.hip
+    render_form): up to 500 000 -- the reference's own default, one environment of 300 x 300 at 100 samples, is such a
+    launch -- the kernel without cooperative tails (render_kernel: one pixel per thread, no barriers: bound by a sample's
+    latency); up to 2.2 M -- examples/ppo_tuned.yml:5: 8 environments -- render_kernel_wave (three sets per wave,
+    wave-cooperative tails, no barriers either: about one round of resident waves); beyond, three pixels per thread with
+    block-cooperative tails.  Same frames, same RNG states, whichever."""
     rng = np.random.default_rng(n * 100 + h)
     d = helpers.pack_scene(*helpers.random_scene(rng, n))
     states = oracle.seed_states(n * h * h, 0)
     want = oracle.render(d[0], d[1], h, h, spp, states, n_threads=16)  # (advances `states` in place)
     automatic = {k: v for k, v in os.environ.items() if k != "REINFOCUS_RENDER_SETS"}
     frames, final, kernel = _render_in_child(tmp_path, d, n, h, spp, automatic, want_kernel=True, replace_env=True)
-    assert kernel.startswith("render_kernel_coop2") == three, kernel
-    assert three or kernel.startswith("render_kernel<"), kernel
+    assert kernel.startswith(form), kernel
     assert np.array_equal(frames, want) and np.array_equal(final, states)
+
+
+@pytest.mark.parametrize("sets", ["w1", "w2", "w3"])
+@pytest.mark.parametrize("n,h,w,spp", [(3, 37, 132, 3), (2, 300, 300, 2), (5, 64, 64, 7), (2, 21, 179, 2), (1, 16, 600, 2),
+                                       (4, 9, 7, 5), (2, 128, 256, 3), (3, 1, 1, 4), (2, 64, 3, 3)])
+def test_wave_cooperative_kernel_matches_oracle(oracle, tmp_path, sets, n, h, w, spp):
+    """render_kernel_wave<POW2, LENS, K> for K = 1, 2, 3 sets per wave (REINFOCUS_RENDER_SETS=w1 / w2 / w3; the library
+    launches K = 3): frames whose pixel count is and is not a multiple of 4 (dword / byte stores), of 64 K, powers of two
+    and not, fewer pixels than one wave has lanes."""
+    rng = np.random.default_rng(n * 1000 + w)
+    d = helpers.pack_scene(*helpers.random_scene(rng, n))
+    states = oracle.seed_states(n * h * w, 0)
+    want = oracle.render(d[0], d[1], h, w, spp, states, n_threads=8)  # (advances `states` in place)
+    frames, final, kernel = _render_in_child(tmp_path, d, n, h, spp, {"REINFOCUS_RENDER_SETS": sets}, w=w, want_kernel=True)
+    assert kernel.startswith("render_kernel_wave<") and (", %s, false>" % sets[1]) in kernel, kernel
+    assert np.array_equal(frames, want), kernel
+    assert np.array_equal(final, states), kernel
 
 
 @pytest.mark.parametrize("h", [64, 50])

@@ -36,6 +36,6 @@ case $job in
     bash profiles/run_profiles.sh "$@" > "$out/run_profiles_$1.log" 2>&1; echo "$1: $(grep -c 'rc=0' "$out/run_profiles_$1.log") passes ok" ;;
   guard)
     [ $# -gt 0 ] && export REINFOCUS_HIP_LIB=$PWD/$1
-    timeout -k 10 300 python -m pytest tests/test_gpu_perf_guard.py -x -q -m gpu > "$out/guard.log" 2>&1; rc=$?; tail -n 4 "$out/guard.log"; exit $rc ;;
+    timeout -k 10 300 python -m pytest tests/test_gpu_perf_guard.py -x -q -m perf > "$out/guard.log" 2>&1; rc=$?; tail -n 4 "$out/guard.log"; exit $rc ;;
   *) echo "unknown job $job"; exit 2 ;;
 esac
