@@ -565,6 +565,9 @@ def cpu_baseline(frame, spp, n_envs, device):
     rf_seed (bit-identical to numba's sequential seeding, tests/test_gpu_parity.py), which
     takes milliseconds where the sequential definition takes ~0.5 s per million states.
     BASELINE.json configs[0] and configs[1] are small enough to be timed in full."""
+    # (OMP_PROC_BIND is honoured when the caller sets it -- it has to be in the environment before the oracle, the process's
+    # first OpenMP code, is loaded -- and recorded in the line; it is not set here: on the GPU boxes, whose jobs get a 16-CPU
+    # share of a 128-thread host, "close" packs the team onto SMT siblings and costs 30 %: profiles/r06_ab.txt section 6)
     from oracle import oracle as orc
     from reinfocus_amd import _native
 
@@ -587,8 +590,18 @@ def cpu_baseline(frame, spp, n_envs, device):
             sweep[team] = 64 / cpu_pass(orc, frame, spp, 64, team, sample.copy(), rng)
         cores = max(sweep, key=sweep.get)
         if n_envs <= 0:
-            n_envs = int(max(cores, min(4096, round(12.0 * sweep[cores]))))
-        dt = cpu_pass(orc, frame, spp, n_envs, cores, seeded(n_envs, frame), rng)
+            n_envs = int(max(cores, min(4096, round(8.0 * sweep[cores]))))
+        # the same sample on both builds of the oracle (oracle/Makefile): -O2, the checker's, and -O3 -march=x86-64-v3 --
+        # both with the parity flags (-ffp-contract=off -fno-fast-math) and both checked against the goldens; the faster one
+        # is the baseline's value
+        builds = []
+        for name in ("o2", "o3"):
+            flags = orc.use_build(name)
+            seconds = cpu_pass(orc, frame, spp, n_envs, cores, seeded(n_envs, frame), rng)
+            builds.append({"build": name, "compiler": flags, "value": n_envs / seconds, "seconds": seconds})
+        best = max(builds, key=lambda b: b["value"])
+        orc.use_build(best["build"])
+        dt = best["seconds"]
         others = []
         for label, n, h, s in (("configs[0]: 1 env x 64x64 x 1 spp", 1, 64, 1),
                                ("configs[1]: 256 envs x 128x128 x 4 spp", 256, 128, 4)):
@@ -598,13 +611,16 @@ def cpu_baseline(frame, spp, n_envs, device):
                            "cores": team})
     finally:
         ctx.close()
+        orc.use_build("o2")
     return {"value": n_envs / dt, "unit": "env-steps/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "builds": builds, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
             "visible_cores": visible, "cgroup_cpu_quota": cgroup_cpu_quota(),
             "thread_sweep_env_steps_per_s": {str(k): v for k, v in sweep.items()},
             "kind": "port",
             "sample": f"{n_envs} envs x {frame}x{frame} x {spp} spp, each with its own seeded RNG states: one "
-                      f"render + focus pass of the C oracle (OpenMP, {cores} threads: the fastest team of a sweep "
-                      f"up to all {visible} visible cores), {dt:.1f} s",
+                      f"render + focus pass of the C oracle (the faster of its -O2 and -O3 -march=x86-64-v3 builds: "
+                      f"{best['build']}; OpenMP, {cores} threads: the fastest team of a sweep "
+                      f"up to all {visible} visible cores; OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}), {dt:.1f} s",
             "other_configs": others}
 
 
@@ -730,6 +746,9 @@ def main(argv=None):
     ranks.barrier()
     elapsed = ranks.reduce(elapsed_local, "MAX")
     total_resets = ranks.reduce(resets, "SUM")
+    # every rank's own time per step (its steps + its share of the gather), in rank order: a straggling rank -- a GPU behind
+    # another PCIe root, a rank on the wrong NUMA node -- is visible in the line, not only in the maximum
+    per_rank_ms = [1000.0 * seconds / max(args.steps, 1) for seconds in ranks.gather(elapsed_local)]
 
     timing = None
     if env is not None and not args.no_kernel_timing:
@@ -757,6 +776,7 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
+            "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

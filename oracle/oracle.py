@@ -26,30 +26,53 @@ class CamStatic(ctypes.Structure):
     ]
 
 
+BUILDS = {"o2": "librf_oracle.so", "o3": "librf_oracle_o3.so"}  # oracle/Makefile: the checker (-O2), and the same source
+                                                                  # at -O3 -march=x86-64-v3 for bench.py's cpu_baseline
+
+
 def build(force=False):
     """Compiles the oracle with gcc (no FMA contraction) where the sources are edited.  On the GPU box
-    (/dev/kfd exists) nothing is compiled: the library that travelled with the checkout must be the
-    build of the sources next to it (its .srchash, written by the Makefile, must still match)."""
+    (/dev/kfd exists) nothing is compiled: the libraries that travelled with the checkout must be the
+    builds of the sources next to them (their .srchash, written by the Makefile, must still match)."""
     if os.path.exists("/dev/kfd"):
         import hashlib
 
-        stamp = _SO + ".srchash"
-        assert os.path.exists(_SO) and os.path.exists(stamp), f"{_SO} (+ .srchash) missing: run __graft_entry__.build()"
-        for line in open(stamp).read().splitlines():
-            digest, path = line.split()
-            now = hashlib.sha256(open(os.path.join(_HERE, path), "rb").read()).hexdigest()
-            assert now == digest, f"{_SO} is stale: {path} changed since it was built"
+        for name in BUILDS.values():
+            so = os.path.join(_HERE, name)
+            stamp = so + ".srchash"
+            assert os.path.exists(so) and os.path.exists(stamp), f"{so} (+ .srchash) missing: run __graft_entry__.build()"
+            for line in open(stamp).read().splitlines():
+                if line.startswith("flags:"):
+                    continue
+                digest, path = line.split()
+                now = hashlib.sha256(open(os.path.join(_HERE, path), "rb").read()).hexdigest()
+                assert now == digest, f"{so} is stale: {path} changed since it was built"
         return _SO
     src = os.path.join(_HERE, "rf_oracle.c")
-    if (
-        force
-        or not os.path.exists(_SO)
-        or not os.path.exists(_SO + ".srchash")
-        or os.path.getmtime(_SO) < os.path.getmtime(src)
-        or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "rf_oracle.h"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "librf_oracle.so"])
+    for name in BUILDS.values():
+        so = os.path.join(_HERE, name)
+        if (
+            force
+            or not os.path.exists(so)
+            or not os.path.exists(so + ".srchash")
+            or os.path.getmtime(so) < os.path.getmtime(src)
+            or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "rf_oracle.h"))
+        ):
+            subprocess.check_call(["make", "-C", _HERE, "-B", name])
     return _SO
+
+
+def use_build(name):
+    """Switches every function of this module to another build of the same source ("o2": the checker, the default; "o3":
+    bench.py's cpu_baseline times both).  Returns the compiler line of that build."""
+    global _SO, _lib
+    _SO = os.path.join(_HERE, BUILDS[name])
+    _lib = None
+    build()
+    for line in open(_SO + ".srchash").read().splitlines():
+        if line.startswith("flags:"):
+            return line[len("flags:"):].strip()
+    return "gcc -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp"
 
 
 _lib = None

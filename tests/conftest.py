@@ -48,7 +48,7 @@ def pytest_sessionstart(session):
 
     hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     have_hipcc = os.path.exists(hipcc)
-    for directory, target, needs_hipcc in (("reinfocus_amd/csrc", "all", True), ("oracle", "librf_oracle.so", False),
+    for directory, target, needs_hipcc in (("reinfocus_amd/csrc", "all", True), ("oracle", "all", False),
                                            ("tests/hostsim", "libhostsim.so", False), ("tests/gpucheck", "all", True)):
         if needs_hipcc and not have_hipcc:
             warnings.warn(f"no hipcc on this host: {directory} is not built")
@@ -67,6 +67,7 @@ def shipped_libraries_match_their_sources():
 
         helpers.verify_srchash(os.path.join(ROOT, "reinfocus_amd/libreinfocus_hip.so"), extra="")  # no -D options
         helpers.verify_srchash(os.path.join(ROOT, "oracle/librf_oracle.so"))
+        helpers.verify_srchash(os.path.join(ROOT, "oracle/librf_oracle_o3.so"))
     yield
 
 

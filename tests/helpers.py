@@ -30,7 +30,7 @@ def verify_srchash(library, extra=None):
     recorded_extra = [line[len("extra:"):].strip() for line in text if line.startswith("extra:")]
     if extra is not None:
         assert recorded_extra == [extra], f"{library} was built with options {recorded_extra}, wanted [{extra!r}]"
-    lines = [line.split() for line in text if not line.startswith("extra:")]
+    lines = [line.split() for line in text if not line.startswith(("extra:", "flags:"))]
     assert lines, f"{stamp} is empty"
     for digest, path in lines:
         source = next((os.path.join(b, path) for b in bases if os.path.exists(os.path.join(b, path))), None)

@@ -53,6 +53,38 @@ def test_two_ranks_over_gloo():
     assert "gathered on rank 0" in line["config"]["sharding"]
 
 
+def test_eight_ranks_over_gloo_with_eight_distinct_gpus():
+    """BASELINE.json configs[3] as the driver launches it -- 8 ranks x 4096 environments -- without GPUs: the self-launcher,
+    the rendezvous, every step's 32 768 x 29 bytes gathered on rank 0, the table of eight distinct (fake) PCI bus ids in rank
+    order, every rank's own time per step, and the launcher's wall time (eight interpreters with torch on this host's
+    eight cores)."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    buses = ["0000:%02x:00.0@%d" % (0x05 + 0x20 * g, g // 4) for g in range(8)]
+    env["REINFOCUS_BENCH_FAKE_DEVICES"] = ",".join(buses)
+    started = time.monotonic()
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--plumbing-test", "--steps", "5", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.monotonic() - started
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 4096 and line["config"]["total_envs"] == 32768
+    assert line["config"]["host_gather_bytes_per_step"] == 29 * 32768
+    assert [(d["rank"], d["pci_bus_id"], d["numa_node"]) for d in line["devices"]] == \
+        [(g, buses[g].split("@")[0], g // 4) for g in range(8)]
+    assert len(line["per_rank_ms_per_step"]) == 8 and all(ms > 0 for ms in line["per_rank_ms_per_step"])
+    assert max(line["per_rank_ms_per_step"]) <= line["ms_per_step"] * 1.001  # the line's time is the slowest rank's
+    assert wall < 300, wall
+    # seven distinct GPUs for eight ranks is not an 8-GPU measurement
+    env["REINFOCUS_BENCH_FAKE_DEVICES"] = ",".join(buses[:7] + [buses[3]])
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--plumbing-test", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and "both ran on the GPU at " + buses[3].split("@")[0] in out.stderr
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2 ...` with no launcher around it: the parent starts the two ranks
     (before anything could touch a GPU), relays rank 0's line and exits 0."""

@@ -88,3 +88,38 @@ def test_render_threads_do_not_change_results(oracle):
     fa = oracle.render(d[0], d[1], 24, 24, 3, a, n_threads=1)
     fb = oracle.render(d[0], d[1], 24, 24, 3, b, n_threads=8)
     assert np.array_equal(fa, fb) and np.array_equal(a, b)
+
+
+def test_the_o3_build_of_the_oracle_gives_the_same_bits(oracle, golden_dir):
+    """bench.py's cpu_baseline also times the oracle at -O3 -march=x86-64-v3 (oracle/Makefile: librf_oracle_o3.so, parity
+    flags intact): the same frames, RNG states and focus values as the checker's -O2 build -- the numpy-1.26 goldens, a
+    random scene, and the general renderer's arithmetic."""
+    from tests.test_general_renderer import _random_scene
+
+    rng = np.random.default_rng(5)
+    t, f = helpers.random_scene(rng, 4)
+    d = helpers.pack_scene(t, f)
+    cameras, (params, types, sizes) = _random_scene(np.random.default_rng(6), 3)
+    results = {}
+    try:
+        for build in ("o2", "o3"):
+            flags = oracle.use_build(build)
+            assert "-ffp-contract=off" in flags and "-fno-fast-math" in flags, flags
+            for name in ("render_pow2", "render_npot", "render_mid"):
+                g = _load(golden_dir, name)
+                h, w, spp = int(g["h"]), int(g["w"]), int(g["spp"])
+                dyn, rect, origin, u, v, lens = helpers.pack_scene(g["targets"], g["focus"], float(g["r_size"]))
+                st = oracle.seed_states(len(g["targets"]) * h * w, 0)
+                for p in range(int(g["passes"])):
+                    frames = oracle.render(dyn, rect, h, w, spp, st, cs=oracle.cam_static(origin, u, v, lens))
+                    assert np.array_equal(frames, g["frames%d" % p]), (build, name)
+                assert np.array_equal(st, g["states_after"]), (build, name)
+            st = oracle.seed_states(4 * 50 * 70, 0)
+            frames = oracle.render(d[0], d[1], 50, 70, 9, st, n_threads=4)
+            st2 = oracle.seed_states(3 * 40 * 33, 0)
+            general = oracle.render_general(cameras, params, types, sizes, 40, 33, 5, st2, n_threads=4)
+            results[build] = (frames, st.copy(), oracle.focus_values(frames), general, st2.copy())
+    finally:
+        oracle.use_build("o2")
+    for a, b in zip(results["o2"], results["o3"]):
+        assert np.array_equal(a, b)

@@ -13,6 +13,8 @@ if [ "$job" = profiles ]; then
   run ${tag}_ref300 "--envs-per-gpu 512 --frame 300 --spp 100" 20
   run ${tag}_c4 "--envs-per-gpu 128 --frame 512 --spp 64" 20
   run ${tag}_c1 "--envs-per-gpu 256 --frame 128 --spp 4" 200
+  run ${tag}_ref8 "--envs-per-gpu 8 --frame 300 --spp 100" 100   # the reference's training shape: render_kernel_wave
+  run ${tag}_env1 "--envs-per-gpu 1 --frame 300 --spp 100" 200   # the reference's default environment: render_kernel
   for scene in one_rect one_sphere two_sphere mixed; do run ${tag}_general_$scene "256 256 16 --scene $scene" 0 tools/bench_general.py; done
   exit 0
 fi
@@ -30,6 +32,8 @@ $B --envs-per-gpu 1024 --frame 512 --spp 64 --steps 5 --warmup 1 > $OUT/bench_c4
 $B --envs-per-gpu 512 --frame 300 --spp 100 --steps 20 --warmup 3 > $OUT/bench_ref300.json 2>> $OUT/err.log
 $B --envs-per-gpu 1 --frame 64 --spp 1 --steps 3000 --warmup 20 --no-kernel-timing > $OUT/bench_c0_gpu.json 2>> $OUT/err.log
 $B --envs-per-gpu 1 --frame 300 --spp 100 --steps 500 --warmup 20 --no-kernel-timing > $OUT/bench_default_env.json 2>> $OUT/err.log
+$B --envs-per-gpu 8 --frame 300 --spp 100 --steps 300 --warmup 20 --no-kernel-timing > $OUT/bench_ref8.json 2>> $OUT/err.log
+$B --envs-per-gpu 16 --frame 256 --spp 16 --steps 500 --warmup 20 --no-kernel-timing > $OUT/bench_16x256.json 2>> $OUT/err.log
 for e in device host literal; do $B --steps 20 --warmup 3 --env $e > $OUT/route_$e.json 2>> $OUT/err.log; done
 export REINFOCUS_BENCH_DEVICE=0
 timeout -k 10 600 $B --gpus 8 --sharded-env --steps 10 --warmup 2 > $OUT/rehearsal_sharded8_one_device.json 2>> $OUT/err.log; echo "sharded8 rc=$?"
