@@ -95,8 +95,8 @@ static bool lens_f32_exact(double radius, float hi, float lo)
 }
 
 // What the process knows about lens radii.  The reference's aperture 0.1 (camera.py:106: FastCameras and make_gpu_camera's
-// default) is entered as proven -- tests/test_hostsim.py::test_lens_offset_float32_form runs the proof on the same
-// arithmetic -- so that no process pays for it; everything else is proven on demand, OUTSIDE the lock (two threads may prove the
+// default) is entered as proven -- the CPU test suite runs the proof on the same arithmetic (test_lens_offset_float32_form)
+// -- so that no process pays for it; everything else is proven on demand, OUTSIDE the lock (two threads may prove the
 // same radius at the same time: same answer), so that contexts on other threads never wait 60 ms for a mutex.
 namespace {
 struct LensRecord {

@@ -374,10 +374,22 @@ RF_HD void disc_finish(const uint32_t w[4], float &p0, float &p1)
     p1 = exact_pm1(w[2], w[3]);
 }
 
+// The in-place rejection loops of render_kernel make two attempts per trip: a launch of few blocks is bound by one wave's
+// latency, and a taken branch costs that wave more than the instructions around it (1 x 300^2 x 100: 252 -> 245 us per step;
+// three per trip: no further gain; profiles/r06_ab.txt section 9).
+#ifndef RF_LOOP_UNROLL
+#define RF_LOOP_UNROLL 2
+#endif
 RF_HD void disc_sample(Rng &g, float &p0, float &p1)
 {
     uint32_t w[4];
-    while (!disc_attempt(g, w)) {
+    for (;;) {
+        if (disc_attempt(g, w))
+            break;
+#if RF_LOOP_UNROLL >= 2
+        if (disc_attempt(g, w))
+            break;
+#endif
     }
     disc_finish(w, p0, p1);
 }
@@ -439,7 +451,17 @@ RF_HD void sphere_finish(const uint32_t w[6], float &q0, float &q1, float &q2)
 RF_HD void sphere_sample(Rng &g, float &q0, float &q1, float &q2)
 {
     uint32_t w[6];
-    while (!sphere_attempt(g, w)) {
+    for (;;) {
+        if (sphere_attempt(g, w))
+            break;
+#if RF_LOOP_UNROLL >= 2
+        if (sphere_attempt(g, w))
+            break;
+#endif
+#if RF_LOOP_UNROLL >= 3
+        if (sphere_attempt(g, w))
+            break;
+#endif
     }
     sphere_finish(w, q0, q1, q2);
 }
