@@ -160,6 +160,47 @@ __device__ __forceinline__ uint4 *entry16(uint4 *array, int offset)
     return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(array) + offset);
 }
 
+// the workers' loops: RF_COOP_UNROLL attempts per trip (a worker wave is what the block's other waves wait for at the next
+// barrier; a taken branch costs it more than the instructions around it: two per trip +0.5 ... 0.9 % env-steps/s at the
+// headline, three and four no more -- profiles/r06_ab.txt section 11)
+#ifndef RF_COOP_UNROLL
+#define RF_COOP_UNROLL 2
+#endif
+__device__ __forceinline__ void sphere_until_accepted(Rng &wg, uint32_t (&ww)[6])
+{
+    for (;;) {
+        if (sphere_attempt(wg, ww))
+            break;
+#if RF_COOP_UNROLL >= 2
+        if (sphere_attempt(wg, ww))
+            break;
+#endif
+#if RF_COOP_UNROLL >= 3
+        if (sphere_attempt(wg, ww))
+            break;
+#endif
+#if RF_COOP_UNROLL >= 4
+        if (sphere_attempt(wg, ww))
+            break;
+#endif
+    }
+}
+__device__ __forceinline__ void disc_until_accepted(Rng &wg, uint32_t (&ww)[6])
+{
+    for (;;) {
+        if (disc_attempt(wg, ww))
+            break;
+#if RF_COOP_UNROLL >= 2
+        if (disc_attempt(wg, ww))
+            break;
+#endif
+#if RF_COOP_UNROLL >= 3
+        if (disc_attempt(wg, ww))
+            break;
+#endif
+    }
+}
+
 typedef unsigned long long lanemask;
 // a block-uniform integer condition, compared where it is used (s_cmp + s_cbranch_scc): hoisted out of the sample loop
 // as a boolean it becomes a lane mask that vector instructions test
@@ -220,8 +261,7 @@ __device__ __forceinline__ void coop_workers(CoopLds2 &lds, int parity, int *cnt
             const int own = lds.owner[tid];
             Rng wg{ps.x, ps.y, ps.z, ps.w};
             uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-            while (!sphere_attempt(wg, ww)) {
-            }
+            sphere_until_accepted(wg, ww);
             state[own] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
             lds.words4[own] = RF_WORDS4(ww);
             lds.words2[own] = RF_WORDS2(ww);
@@ -234,13 +274,10 @@ __device__ __forceinline__ void coop_workers(CoopLds2 &lds, int parity, int *cnt
             const uint4 ps = state[tid];
             Rng wg{ps.x, ps.y, ps.z, ps.w};
             uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-            if (DIM == 2) {
-                while (!disc_attempt(wg, ww)) {
-                }
-            } else {
-                while (!sphere_attempt(wg, ww)) {
-                }
-            }
+            if (DIM == 2)
+                disc_until_accepted(wg, ww);
+            else
+                sphere_until_accepted(wg, ww);
             state[tid] = make_uint4(wg.a_lo, wg.a_hi, wg.b_lo, wg.b_hi);
             lds.words4[tid] = RF_WORDS4(ww);
             if (DIM == 3)
@@ -392,8 +429,7 @@ __device__ __forceinline__ void disc_tails_wave(uint4 *region, const lanemask (&
         const uint4 ps = region[tid];
         wg = Rng{ps.x, ps.y, ps.z, ps.w};
         uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-        while (!disc_attempt(wg, ww)) {
-        }
+        disc_until_accepted(wg, ww);
         region[tid] = RF_WORDS4(ww); // the accepted draws first: the worker keeps the four state words meanwhile
     }
     wave_lds_order();

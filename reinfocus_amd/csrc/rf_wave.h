@@ -39,6 +39,9 @@ namespace rf {
 #ifndef RF_WAVE_PRIO
 #define RF_WAVE_PRIO 0
 #endif
+#ifndef RF_WAVE_UNROLL
+#define RF_WAVE_UNROLL 1
+#endif
 
 // sets whose colour sums live in LDS (the others: registers)
 template <int K>
@@ -116,7 +119,13 @@ __device__ __forceinline__ void tails_wave(WaveLds<K> &lds, lanemask (&need)[K],
         const uint4 ps = lds.slot[lane];
         wg = Rng{ps.x, ps.y, ps.z, ps.w};
         uint32_t ww[6] = {0, 0, 0, 0, 0, 0};
-        while (!attempt<DIM>(wg, ww)) {
+        for (;;) { // (RF_WAVE_UNROLL attempts per trip: see rf_coop2.h RF_COOP_UNROLL)
+            if (attempt<DIM>(wg, ww))
+                break;
+#if RF_WAVE_UNROLL >= 2
+            if (attempt<DIM>(wg, ww))
+                break;
+#endif
         }
         lds.slot[lane] = RF_WORDS4(ww); // the accepted draws first: the worker keeps the four state words meanwhile
         if (DIM == 3)
