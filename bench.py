@@ -382,7 +382,7 @@ def derive_pmc(e, kernel):
         e["pixels_per_wave"] = e["pixels"] / e["SQ_WAVES"]
         e["pixels_from"] = "rf_pixels_rendered of the profiled run"
     else:
-        e["pixels_per_wave"] = 192 if "render_kernel_coop2" in kernel else 64
+        e["pixels_per_wave"] = 192 if ("render_kernel_coop2" in kernel or "render_kernel_wave" in kernel) else 64  # (the wave kernel: K = 3)
         e["pixels_from"] = "SQ_WAVES x pixels per wave (padded lanes included)"
     if e.get("SQ_WAVES") and "SQ_INSTS_VALU" in e:
         e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]

@@ -77,7 +77,7 @@ def main(tag):
             e["pixels_per_wave"] = e["pixels"] / e["SQ_WAVES"]
             e["pixels_from"] = "rf_pixels_rendered of the profiled run"
         elif "render_kernel" in k:
-            e["pixels_per_wave"] = 192 if "render_kernel_coop2" in k else 64
+            e["pixels_per_wave"] = 192 if ("render_kernel_coop2" in k or "render_kernel_wave" in k) else 64  # (the wave kernel: K = 3)
             e["pixels_from"] = "SQ_WAVES x pixels per wave (padded lanes included)"
         # sustained shader clock under this kernel: GRBM_GUI_ACTIVE counts every XCD's busy cycles
         if e.get("GRBM_GUI_ACTIVE") and spans.get(k):
