@@ -57,8 +57,8 @@ struct WaveLds {
 #if RF_WAVE_STATE_OUT
     uint4 state_out[64];
 #endif
-    float colour[WaveTune<K>::colour_lds > 0 ? WaveTune<K>::colour_lds : 1][3][64]; // colour sums of the sets that keep them here
-    float xy[K][2][64];     // frames that are no powers of two: (float)x, (float)y of a lane's pixels
+    float colour[WaveTune<K>::colour_lds > 0 ? WaveTune<K>::colour_lds : 1][3][WaveTune<K>::colour_lds > 0 ? 64 : 1]; // colour sums of the sets that keep them here
+    float xy[RF_WAVE_XY_LDS ? K : 1][2][RF_WAVE_XY_LDS ? 64 : 1]; // (RF_WAVE_XY_LDS) frames that are no powers of two: (float)x, (float)y of a lane's pixels
 };
 
 template <int DIM>
