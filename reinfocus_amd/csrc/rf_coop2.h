@@ -128,8 +128,14 @@ constexpr int kDiscWaveSlots = RF_DISC_WAVE_SLOTS;
 static_assert(kDiscWaveSlots >= 1 && kDiscWaveSlots <= 64, "a wave's quarter of state[0]");
 
 constexpr int kCoopTrips2 = 1;      // in-wave sphere attempts before the cooperative call
-constexpr int kTwoRoundsMin = 64;   // sphere entries above which the packing round is used
-constexpr int kRound1Sphere = 2;    // attempts per entry in the packing round
+#ifndef RF_TWO_ROUNDS_MIN
+#define RF_TWO_ROUNDS_MIN 64
+#endif
+#ifndef RF_ROUND1_SPHERE
+#define RF_ROUND1_SPHERE 2
+#endif
+constexpr int kTwoRoundsMin = RF_TWO_ROUNDS_MIN;   // sphere entries above which the packing round is used
+constexpr int kRound1Sphere = RF_ROUND1_SPHERE;    // attempts per entry in the packing round
 constexpr int kAdaptOn = 32, kAdaptOff = -32; // hysteresis of the per-block switch between one and two in-wave attempts
 constexpr int kColourLds = 2;       // pixel sets whose colour sums live in LDS
 #ifndef RF_TAIL_PRIO

@@ -1,5 +1,7 @@
 """TEST INFRASTRUCTURE (not collected by pytest): randomised parity soak of the render + focus path
-against the CPU oracle.  usage (GPU box, repo root): python tests/soak/soak_render.py [cases] [seed]"""
+against the CPU oracle.  usage (GPU box, repo root): python tests/soak/soak_render.py [cases] [seed]
+REINFOCUS_RENDER_SETS=3 / w3 / w2 / w1 / 1 in the environment forces one render kernel for every case (default: the
+library's choice by launch size); the kernels that rendered are counted and printed."""
 import sys
 import time
 
@@ -17,6 +19,7 @@ def main():
     oracle.build()
     ctx = _native.Context(0)
     t0 = time.time()
+    kernels = {}
     for case in range(cases):
         h = int(rng.choice([16, 31, 64, 96, 100, 128, 130, 200, 256, 300]))
         w = h if rng.random() < 0.7 else int(rng.integers(1, 400))
@@ -34,6 +37,8 @@ def main():
         for p in range(passes):
             want = oracle.render(d[0], d[1], h, w, spp, st, n_threads=8)
             got = ctx.render(n, h, w, spp, to_host=True)
+            name = ctx.render_kernel_name().split("<")[0]
+            kernels[name] = kernels.get(name, 0) + 1
             assert np.array_equal(got, want), (case, p, n, h, w, spp, r_size)
             fv = ctx.focus(n, h, w)
             ref = np.array(oracle.focus_values(want))
@@ -42,7 +47,7 @@ def main():
         print(f"case {case}: n={n} {h}x{w} spp={spp} r_size={r_size} passes={passes} ok ({time.time() - t0:.0f} s)",
               flush=True)
     ctx.close()
-    print("soak ok")
+    print(f"soak ok: {cases} cases, kernels {kernels}")
 
 
 if __name__ == "__main__":

@@ -45,6 +45,8 @@ for f in $OUT/bench_*.json $OUT/route_*.json $OUT/rehearsal_*.json; do python -c
 import json; d=json.loads([l for l in open('$f') if l.startswith('{')][-1]); print('$f', d['n_gpus'], round(d['value'],1), round(d['ms_per_step'],4), d['config']['workload'][:60], len(d['devices']), d['config'].get('host_gather_bytes_per_step'))"; done
 cat $OUT/bench_general.txt $OUT/bench_general_300.txt
 { echo "## tests/soak/soak_render.py 600 25"; timeout -k 10 900 python tests/soak/soak_render.py 600 25 2>&1 | tail -n 2
+  for sets in w3 w2 3; do echo "## REINFOCUS_RENDER_SETS=$sets tests/soak/soak_render.py 400 26"; REINFOCUS_RENDER_SETS=$sets timeout -k 10 900 python tests/soak/soak_render.py 400 26 2>&1 | tail -n 1; done
+  echo "## tests/soak/soak_focus.py 300 27"; timeout -k 10 900 python tests/soak/soak_focus.py 300 27 2>&1 | tail -n 1
   echo "## tests/soak/soak_general.py 800 25"; timeout -k 10 600 python tests/soak/soak_general.py 800 25 2>&1 | tail -n 2
   echo "## tools/soak_env.py 250 25"; timeout -k 10 600 python tools/soak_env.py 250 25 2>&1 | tail -n 2; } > $OUT/soaks.txt 2>&1
 cat $OUT/soaks.txt
