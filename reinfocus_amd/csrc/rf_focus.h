@@ -1,6 +1,9 @@
-// rf_focus.h -- the focus measure of vision.focus_value (vision.py:23-25):
-//   focus_kernel / focus_kernel_quad   cvtColor -> medianBlur(3) -> Laplacian(CV_8U) -> per-env integer sums
-//   focus_finalize                     ndarray.var() from the exact sums
+// rf_focus.h -- the focus measure of vision.focus_value (vision.py:23-25): cvtColor -> medianBlur(3) -> Laplacian(CV_8U) ->
+// per-env integer sums -> ndarray.var() from the exact sums.
+//   focus_kernel_roll   widths that are multiples of 4 (>= 8): four pixels per lane, rows rolling through registers (round 6)
+//   focus_kernel        any other width: a byte per thread over column tiles of 512, the chain through LDS
+//   focus_kernel_quad   the round-2 kernel (whole rows staged in LDS, widths up to 936 px): A/B runs and tests only
+//   focus_finalize      the variance (rf_math.h variance_from_sums)
 #pragma once
 
 #include "rf_common.h"
@@ -9,7 +12,7 @@ namespace rf {
 
 // ---------------------------------------------------------------------------
 // focus: gray -> median3x3 (replicate) -> Laplacian (reflect-101, sat u8) -> sums
-// One block per (row band, env).  Integer/byte work, HBM-bound: 3 B/pixel read.
+// One block per (row band, column tile, env).  Integer/byte work: 3 B/pixel read.
 // ---------------------------------------------------------------------------
 constexpr int kBand = 16; // output rows per block
 
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(kBlock) void focus_kernel_quad(FocusArgs a)
 //     one atomic pair per wave at the end.
 // Rows above / below the frame: gray rows replicate (the row index is clamped: medianBlur's BORDER_REPLICATE), the
 // Laplacian's reflect-101 takes the row below for the row above at y = 0 (and the reverse at y = h - 1).
-// A step costs ~100 vector instructions for 4 x 62 (64) pixels: 0.4 per pixel and lane.
+// A step costs 129 vector instructions for 4 x 62 (64) pixels, nearly all of gfx950's slow issue class (0.24 per cycle and
+// SIMD): the headline's 4625 frames of 256^2 in 0.24 ms = 3.9 TB/s of the 3 B/pixel it reads (profiles/r06_ab.txt section 1).
 // ---------------------------------------------------------------------------
 struct GrayDot {                // RGB2GRAY by v_dot4_u32_u8: coefficient bytes for a pixel in bytes 0..2 / 1..3 of a dword
     uint32_t hi_lo3, lo_lo3;    // high / low bytes of the three coefficients at byte positions 0, 1, 2
