@@ -308,6 +308,46 @@ def test_sb3_wrapper_over_device_environment():
     plain.close()
 
 
+def test_sb3_rollout_over_the_device_environment_equals_the_numpy_glue():
+    """The adapter as stable-baselines3's on-policy rollout drives a VecEnv (vector_shim.py:63-93 under
+    OnPolicyAlgorithm.collect_rollouts: reset once, then step_async / step_wait, the bootstrap value taken from
+    infos[i]["terminal_observation"] wherever dones[i]) over the device-resident environment -- against the same adapter over the
+    numpy-glue environment, an independent implementation of the step (transformer, enders, rewarder, normaliser in numpy around
+    rf_render / rf_focus): observations, rewards, dones, terminal observations, the attribute plumbing and the rendered images."""
+    from reinfocus_amd.environments import harness, vector_shim
+
+    kwargs = dict(max_episode_steps=4, num_envs=5, frame_height=64, samples_per_pixel=4, seed=21, device=0, render_mode="rgb_array")
+    device = vector_shim.SB3Wrapper(harness.DeviceVectorDiscreteSteps(**kwargs), "rgb_array")
+    glue = vector_shim.SB3Wrapper(harness.VectorDiscreteSteps(**kwargs), "rgb_array")
+    try:
+        assert device.num_envs == glue.num_envs == 5
+        assert device.get_attr("num_envs") == glue.get_attr("num_envs") == [5] * 5
+        assert device.get_attr("num_envs", [0, 3]) == [5, 5] and device.env_is_wrapped(object) == [False] * 5
+        last = [device.reset(), glue.reset()]
+        assert np.array_equal(*last)
+        generator = np.random.default_rng(8)
+        bootstrapped = 0
+        for step in range(9):
+            actions = generator.integers(0, 13, size=5)
+            device.step_async(actions)
+            glue.step_async(actions)
+            results = [device.step_wait(), glue.step_wait()]
+            for got, want in zip(results[0][:3], results[1][:3]):
+                assert got.dtype == want.dtype and np.array_equal(got, want), step
+            for info_d, info_g, done in zip(results[0][3], results[1][3], results[0][2]):
+                assert ("terminal_observation" in info_d) == ("terminal_observation" in info_g) == bool(done)
+                if done:
+                    assert np.array_equal(info_d["terminal_observation"], info_g["terminal_observation"])
+                    bootstrapped += 1
+            if step in (2, 7):  # (the visualiser's 600 px render re-seeds / advances the RNG states the next step uses: both alike)
+                images = [device.get_images(), glue.get_images()]
+                assert len(images[0]) == len(images[1]) == 1 and np.array_equal(images[0][0], images[1][0])
+        assert bootstrapped >= 10
+    finally:
+        device.close()
+        glue.close()
+
+
 def test_registered_vector_env_is_device_resident_and_reproduces_the_notebook():
     """The env id's vector entry point (examples/__init__.py:6-11) builds the device-resident
     environment -- the one bench.py measures -- and, with render_mode="rgb_array", that environment
