@@ -860,8 +860,14 @@ def main(argv=None):
             out["roofline_valu"] = valu if valu is not None else {"unavailable": why_not, "from_committed_profile": True}
             if pmc_failure:
                 out["roofline"]["pmc_failure"] = pmc_failure
-            out["focus_kernel"] = {
-                "achieved_GBps": FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9 if focus_s > 0 else None,
+            focus_gbps = FOCUS_BYTES_PER_PIXEL * pixels / focus_s / 1e9 if focus_s > 0 else None
+            out["focus_kernel"] = {  # north_star's second kernel: its nominated roof (HBM) is its real one
+                "kernel": "focus_kernel_roll" if frame % 4 == 0 and frame >= 8 else "focus_kernel",
+                "bound": "hbm",
+                "achieved_GBps": focus_gbps,
+                "peak_GBps": 8000.0,
+                "frac": focus_gbps / 8000.0 if focus_gbps else None,
+                "algorithmic_bytes_per_pixel": FOCUS_BYTES_PER_PIXEL,
                 "avg_launch_ms": timing["focus_ms"] / max(timing["focus_launches"], 1),
                 "launches": timing["focus_launches"],
             }
