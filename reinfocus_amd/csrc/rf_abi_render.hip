@@ -349,6 +349,8 @@ int launch_focus(rf_ctx *ctx, int n, int h, int w, int gray_mode, const float *s
         int band = 8;
         if (roll) {
             for (int r = rf::kRollBandMax; r >= 8; r >>= 1) {
+                if (r >= 2 * h && r > 8) // (a band taller than the frame only walks rows that do not exist)
+                    continue;
                 const uint64_t lanes = (uint64_t)((h + r - 1) / r) * groups;
                 const uint64_t waves = (lanes + (halo ? 61 : 63)) / (halo ? 62 : 64) * (uint64_t)rows;
                 if (waves >= 8192 || r == 8) {
