@@ -71,7 +71,7 @@ def _measure():
     ctx.focus(n, h, h, 15)
     ctx.timing(True)
     times = []
-    for _ in range(4):
+    for _ in range(16):  # (0.12 ms launches: the best of sixteen -- single launches were measured 3.0 ... 3.4 TB/s on one box)
         ms = ctx.timing_read()["focus_ms"]
         ctx.focus(n, h, h, 15)
         times.append(ctx.timing_read()["focus_ms"] - ms)
