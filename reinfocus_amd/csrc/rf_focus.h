@@ -405,18 +405,16 @@ __global__ __launch_bounds__(64) void focus_kernel_roll(FocusRollArgs ra)
     const GrayDot &k = ra.dot;
     auto gray_row = [&](const Rgb4 &p, GrayRow6 &g) {
         const uint32_t p1 = __builtin_amdgcn_alignbyte(p.d1, p.d0, 3), p2 = __builtin_amdgcn_alignbyte(p.d2, p.d1, 2);
-        const uint32_t l0 = __builtin_amdgcn_udot4(p.d0, k.lo_lo3, k.round, false);
-        const uint32_t l1 = __builtin_amdgcn_udot4(p1, k.lo_lo3, k.round, false);
-        const uint32_t l2 = __builtin_amdgcn_udot4(p2, k.lo_lo3, k.round, false);
-        const uint32_t l3 = __builtin_amdgcn_udot4(p.d2, k.lo_hi3, k.round, false);
-        const uint32_t h0 = __builtin_amdgcn_udot4(p.d0, k.hi_lo3, 0u, false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(p1, k.hi_lo3, 0u, false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(p2, k.hi_lo3, 0u, false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(p.d2, k.hi_hi3, 0u, false);
-        g.v[1] = ((h0 << 8) + l0) >> k.shift;
-        g.v[2] = ((h1 << 8) + l1) >> k.shift;
-        g.v[3] = ((h2 << 8) + l2) >> k.shift;
-        g.v[4] = ((h3 << 8) + l3) >> k.shift;
+        // (256 H + L + round) >> shift == (H + ((L + round) >> 8)) >> (shift - 8): H is an integer, so the fraction the inner
+        // shift drops cannot carry into the outer floor -- and the shifts right issue on gfx950's fast class, the shift-add does not
+        const uint32_t l0 = __builtin_amdgcn_udot4(p.d0, k.lo_lo3, k.round, false) >> 8;
+        const uint32_t l1 = __builtin_amdgcn_udot4(p1, k.lo_lo3, k.round, false) >> 8;
+        const uint32_t l2 = __builtin_amdgcn_udot4(p2, k.lo_lo3, k.round, false) >> 8;
+        const uint32_t l3 = __builtin_amdgcn_udot4(p.d2, k.lo_hi3, k.round, false) >> 8;
+        g.v[1] = __builtin_amdgcn_udot4(p.d0, k.hi_lo3, l0, false) >> (k.shift - 8);
+        g.v[2] = __builtin_amdgcn_udot4(p1, k.hi_lo3, l1, false) >> (k.shift - 8);
+        g.v[3] = __builtin_amdgcn_udot4(p2, k.hi_lo3, l2, false) >> (k.shift - 8);
+        g.v[4] = __builtin_amdgcn_udot4(p.d2, k.hi_hi3, l3, false) >> (k.shift - 8);
         const uint32_t gl = from_left_lane(g.v[4]), gr = from_right_lane(g.v[1]);
         g.v[0] = left_edge ? g.v[1] : gl;  // BORDER_REPLICATE
         g.v[5] = right_edge ? g.v[4] : gr;
@@ -447,15 +445,32 @@ __global__ __launch_bounds__(64) void focus_kernel_roll(FocusRollArgs ra)
         const int y = y0 + s - 4;
         const bool top = y == 0, bottom = y == h - 1;
         const bool valid = counted && s >= 4 && s < R + 4 && y < h;
+        // the frame's first and last row (reflect-101: the row below stands in for the row above, and the reverse) concern
+        // one lane in hundreds: the selects run only in the steps in which some lane of the wave is there
+        uint32_t up[4], dn[4];
+        if (__builtin_amdgcn_ballot_w64(top || bottom) != 0) { // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                up[i] = top ? mn.v[i + 1] : mu.v[i + 1];
+                dn[i] = bottom ? mu.v[i + 1] : mn.v[i + 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                up[i] = mu.v[i + 1];
+                dn[i] = mn.v[i + 1];
+            }
+        }
+        uint32_t t1 = 0, t2 = 0;
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
-            const uint32_t up = top ? mn.v[i] : mu.v[i], dn = bottom ? mu.v[i] : mn.v[i];
-            int v = (int)(up + dn + mc.v[i - 1] + mc.v[i + 1]) - 4 * (int)mc.v[i];
+            int v = (int)(up[i - 1] + dn[i - 1] + mc.v[i - 1] + mc.v[i + 1]) - 4 * (int)mc.v[i];
             v = min(max(v, 0), 255);
-            v = valid ? v : 0;
-            s1 += (uint32_t)v;
-            s2 += (uint32_t)(v * v);
+            t1 += (uint32_t)v;
+            t2 += (uint32_t)(v * v);
         }
+        s1 += valid ? t1 : 0u; // (one select per sum and step, not per pixel)
+        s2 += valid ? t2 : 0u;
     };
     GrayRow6 ga{}, gb{}, gc{};
     MedRow6 ma{}, mb{}, mc{};
